@@ -1,0 +1,485 @@
+// Methods with a bitmap or full operand or result: the device counterparts of
+//   GB_AxB_dot2   C<#M> = A'*B, C bitmap          (Source/GB_AxB_dot2.c:53)
+//   GB_AxB_dot4   C += A'*B,   C full in place    (Source/GB_AxB_dot4.c:49,
+//                                                  Source/Template/GB_AxB_dot4_template.c:316-711)
+//   GB_AxB_saxpy4 C += A*B, A sparse, B dense     (Source/GB_AxB_saxpy4.c:48)
+//   GB_AxB_saxpy5 C += A*B, A dense,  B sparse    (Source/GB_AxB_saxpy5.c:55)
+//   GB_AxB_saxbit C<#M> = A*B, C bitmap           (Source/GB_AxB_saxbit.c:46)
+// "dense" = bitmap or full.  These are the SpMV / SpMM / frontier-step shapes:
+// one sparse operand is streamed once, coalesced, and the other side is
+// indexed directly.  The CPU code splits the work into coarse / fine-atomic /
+// fine-workspace tasks (Source/GB_AxB_saxpy4_tasks.c:84-103); on the GPU every
+// vector of the sparse operand gets a group of lanes sized to its length, long
+// vectors go to whole workgroups, and cross-lane results are combined with
+// wavefront shuffles (dot) or HBM atomics (saxpy).
+#include "gba_internal.hpp"
+
+namespace gba {
+
+struct DenseView {          // bitmap or full operand, column-major (vector-major)
+    const void *x; const int8_t *b; int64_t vlen; bool iso;
+};
+struct MaskViewD {          // mask for the bitmap-C methods; same meaning as in saxpy3
+    int kind; bool comp, structural, iso; int msize; int64_t vlen;
+    const int64_t *p; const int64_t *i; const int8_t *b; const uint8_t *x;
+};
+
+__device__ inline bool maskd_value(const MaskViewD &m, int64_t p) {
+    if (m.structural) return true;
+    const uint8_t *v = m.x + (m.iso ? 0 : p * m.msize);
+    bool nz = false;
+    for (int q = 0; q < m.msize; q++) nz |= (v[q] != 0);
+    return nz;
+}
+__device__ inline bool maskd_allows(const MaskViewD &m, int64_t i, int64_t j) {
+    if (m.kind == 0) return true;
+    bool mij = false;
+    if (m.kind == 1) {
+        int64_t lo = m.p[j], hi = m.p[j + 1] - 1;
+        while (lo <= hi) {
+            int64_t mid = (lo + hi) >> 1;
+            int64_t v = m.i[mid];
+            if (v < i) lo = mid + 1; else if (v > i) hi = mid - 1; else { mij = maskd_value(m, mid); break; }
+        }
+    } else {
+        const int64_t p = j * m.vlen + i;
+        mij = (m.kind == 2) ? (m.b[p] != 0) : true;
+        if (mij) mij = maskd_value(m, p);
+    }
+    return mij != m.comp;
+}
+
+static gba_info make_maskd(const gba_matrix *M, bool comp, bool structural, MaskViewD *mv) {
+    MaskViewD m{};
+    if (!M) { *mv = m; return GBA_SUCCESS; }
+    if (is_hyper(M)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse mask");
+    if (is_sparse(M) && M->jumbled) GBA_FAIL(GBA_NOT_IMPLEMENTED, "jumbled sparse mask");
+    if (M->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "mask has zombies");
+    m.kind = is_sparse(M) ? 1 : (is_bitmap(M) ? 2 : 3);
+    m.comp = comp; m.structural = structural; m.iso = M->iso; m.msize = (int)type_size(M->type);
+    if (!structural && (m.msize == 0 || !M->x)) GBA_FAIL(GBA_INVALID_OBJECT, "valued mask without values");
+    m.vlen = M->vlen; m.p = M->p; m.i = M->i; m.b = M->b; m.x = reinterpret_cast<const uint8_t *>(M->x);
+    *mv = m;
+    return GBA_SUCCESS;
+}
+
+// ---------------------------------------------------------------- dot2/dot4 --
+// C(i,j) = reduce_k A(k,i) (x) B(k,j): A sparse (vector i lists k), B dense.
+// MODE 0: dot4, Cx full updated in place.  MODE 1: dot2, Cb/Cx written.
+// Each vector i is handled by `lpr` lanes; vectors longer than long_len are
+// only queued for dot_long_kernel.
+template <class S, int MODE>
+__global__ void __launch_bounds__(256)
+dot_sd_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+              const void *__restrict__ Ax_, bool A_iso, DenseView B, MaskViewD M, int lpr, int64_t long_len,
+              typename S::z_t *__restrict__ Cx, int8_t *__restrict__ Cb, int64_t cvlen,
+              unsigned int *__restrict__ nlong, int64_t *__restrict__ long_list) {
+    using X = typename S::x_t; using Z = typename S::z_t;
+    const X *Ax = reinterpret_cast<const X *>(Ax_);
+    const X *Bx = reinterpret_cast<const X *>(B.x);
+    const int64_t j = blockIdx.y;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid / lpr;
+    const int lane = (int)(gid - i * lpr);
+    if (i >= nvecA) return;                         // whole groups leave together (lpr divides 64)
+    const int64_t pA0 = Ap[i], pA1 = Ap[i + 1];
+    const int64_t pC = j * cvlen + i;
+    if (pA1 - pA0 > long_len) {
+        if (lane == 0 && j == 0) { unsigned int q = atomicAdd(nlong, 1u); long_list[q] = i; }
+        return;
+    }
+    if (MODE == 1 && !maskd_allows(M, i, j)) { if (lane == 0) Cb[pC] = 0; return; }
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    const int64_t boff = j * B.vlen;
+    Z acc = sr.identity();
+    int found = 0;
+    for (int64_t p = pA0 + lane; p < pA1; p += lpr) {
+        const int64_t k = Ai[p];
+        if (B.b && !B.b[boff + k]) continue;
+        const X a = load_x<X>(Ax, p, A_iso, apat);
+        const X b = load_x<X>(Bx, boff + k, B.iso, bpat);
+        const Z t = sr.mult(a, b, i, k, j);        // C(i,j) += A'(i,k) (x) B(k,j)
+        acc = found ? sr.add(acc, t) : t;
+        found = 1;
+    }
+    group_reduce(sr, acc, found, lpr);
+    if (lane == 0) {
+        if (MODE == 0) { if (found) Cx[pC] = sr.add(Cx[pC], acc); }
+        else { Cb[pC] = (int8_t)found; if (found) Cx[pC] = acc; }
+    }
+}
+
+template <class S, int MODE>
+__global__ void __launch_bounds__(256)
+dot_long_kernel(S sr, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                const void *__restrict__ Ax_, bool A_iso, DenseView B, MaskViewD M,
+                typename S::z_t *__restrict__ Cx, int8_t *__restrict__ Cb, int64_t cvlen,
+                const unsigned int *__restrict__ nlong, const int64_t *__restrict__ long_list) {
+    using X = typename S::x_t; using Z = typename S::z_t;
+    __shared__ Z part[4];
+    __shared__ int pfound[4];
+    const X *Ax = reinterpret_cast<const X *>(Ax_);
+    const X *Bx = reinterpret_cast<const X *>(B.x);
+    const int64_t j = blockIdx.y;
+    const unsigned int n = *nlong;
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    const int64_t boff = j * B.vlen;
+    for (unsigned int q = blockIdx.x; q < n; q += gridDim.x) {
+        const int64_t i = long_list[q];
+        const int64_t pC = j * cvlen + i;
+        if (MODE == 1 && !maskd_allows(M, i, j)) { if (threadIdx.x == 0) Cb[pC] = 0; continue; }
+        const int64_t pA1 = Ap[i + 1];
+        Z acc = sr.identity();
+        int found = 0;
+        for (int64_t p = Ap[i] + threadIdx.x; p < pA1; p += 256) {
+            const int64_t k = Ai[p];
+            if (B.b && !B.b[boff + k]) continue;
+            const X a = load_x<X>(Ax, p, A_iso, apat);
+            const X b = load_x<X>(Bx, boff + k, B.iso, bpat);
+            const Z t = sr.mult(a, b, i, k, j);
+            acc = found ? sr.add(acc, t) : t;
+            found = 1;
+        }
+        group_reduce(sr, acc, found, 64);
+        if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = acc; pfound[threadIdx.x >> 6] = found; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Z r = sr.identity(); int f = 0;
+            for (int w = 0; w < 4; w++) if (pfound[w]) { r = f ? sr.add(r, part[w]) : part[w]; f = 1; }
+            if (MODE == 0) { if (f) Cx[pC] = sr.add(Cx[pC], r); }
+            else { Cb[pC] = (int8_t)f; if (f) Cx[pC] = r; }
+        }
+        __syncthreads();
+    }
+}
+
+static gba_info count_ones(const int8_t *b, int64_t n, int64_t *out) { return dev_count_ones(b, n, out); }
+
+static int pick_group(const gba_matrix *A) {
+    const double avg = (A->nvec > 0) ? (double)A->nvals / (double)A->nvec : 1.0;
+    int g = 2;
+    while (g < 64 && (double)g < avg) g <<= 1;
+    return g;
+}
+
+template <int MODE>
+static gba_info dot_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
+                                 const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep) {
+    GBA_OK(require_init());
+    if (!is_sparse(A) || !is_dense_fmt(B))
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "dot%d on device: A must be sparse and B bitmap/full (got %d, %d)",
+                 MODE == 0 ? 4 : 2, A->sparsity, B->sparsity);
+    if (A->jumbled && !(c.add == GBA_ANY)) { /* order only matters for fp rounding; any order is a valid sum */ }
+    if (A->vlen != B->vlen) GBA_FAIL(GBA_DIMENSION_MISMATCH, "dot: A->vlen %ld != B->vlen %ld", (long)A->vlen, (long)B->vlen);
+    if (A->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "dot: A has zombies");
+    hipStream_t st = ctx().stream;
+    const int64_t cvlen = A->vdim, cvdim = B->vdim;
+    if (cvdim > 65535) GBA_FAIL(GBA_NOT_IMPLEMENTED, "dot: more than 65535 dense vectors");
+    MaskViewD mv; GBA_OK(make_maskd(M, Mask_comp, Mask_struct, &mv));
+    DevBuf Cb, Cx;
+    const size_t zsize = type_size(c.ztype);
+    if (MODE == 0) {
+        if (!is_full(C) || C->type != c.ztype || C->vlen != cvlen || C->vdim != cvdim || C->iso)
+            GBA_FAIL(GBA_INVALID_VALUE, "dot4: C must be a full non-iso matrix of the monoid type, %ld-by-%ld", (long)cvlen, (long)cvdim);
+    } else {
+        GBA_OK(Cb.alloc((size_t)(cvlen * cvdim > 0 ? cvlen * cvdim : 1)));
+        GBA_OK(Cx.alloc((size_t)(cvlen * cvdim > 0 ? cvlen * cvdim : 1) * zsize));
+    }
+    DevBuf nlong, long_list;
+    GBA_OK(nlong.alloc(4));
+    GBA_OK(long_list.alloc((size_t)(A->nvec > 0 ? A->nvec : 1) * 8));
+    GBA_HIP(hipMemsetAsync(nlong.p, 0, 4, st));
+    KernelTimer timer(rep != nullptr);
+    if (cvlen > 0 && cvdim > 0) {
+        const int lpr = pick_group(A);
+        const int64_t long_len = 8192;
+        DenseView Bv{B->x, is_bitmap(B) ? B->b : nullptr, B->vlen, B->iso};
+        void *cx = (MODE == 0) ? C->x : Cx.p;
+        int8_t *cb = (MODE == 0) ? nullptr : Cb.as<int8_t>();
+        GBA_OK(with_semiring(c, [&](auto sr) -> gba_info {
+            using S = decltype(sr); using Z = typename S::z_t;
+            dim3 grid((unsigned)ceil_div(A->nvec * lpr, 256), (unsigned)cvdim);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(dot_sd_kernel<S, MODE>), grid, dim3(256), 0, st, sr, A->nvec, A->p, A->i,
+                               A->x, A->iso, Bv, mv, lpr, long_len, reinterpret_cast<Z *>(cx), cb, cvlen,
+                               nlong.as<unsigned int>(), long_list.as<int64_t>());
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(dot_long_kernel<S, MODE>), dim3(512, (unsigned)cvdim), dim3(256), 0, st, sr,
+                               A->p, A->i, A->x, A->iso, Bv, mv, reinterpret_cast<Z *>(cx), cb, cvlen,
+                               nlong.as<unsigned int>(), long_list.as<int64_t>());
+            GBA_HIP(hipGetLastError());
+            return GBA_SUCCESS;
+        }));
+    }
+    if (rep) rep->kernel_ms = timer.stop_ms();
+    if (MODE == 1) {
+        int64_t nvals = 0;
+        GBA_OK(count_ones(Cb.as<int8_t>(), cvlen * cvdim, &nvals));
+        C->vlen = cvlen; C->vdim = cvdim; C->nvec = cvdim; C->nvals = nvals;
+        C->p = nullptr; C->h = nullptr; C->i = nullptr;
+        C->b = Cb.as<int8_t>(); Cb.release();
+        C->x = Cx.release();
+        C->nzombies = 0; C->type = c.ztype; C->sparsity = GBA_BITMAP; C->mem = GBA_MEM_DEVICE;
+        C->iso = false; C->jumbled = false;
+    } else {
+        GBA_HIP(hipStreamSynchronize(st));
+    }
+    return GBA_SUCCESS;
+}
+
+gba_info dot2(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
+              const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep) {
+    if (M && (M->vlen != A->vdim || M->vdim != B->vdim)) GBA_FAIL(GBA_DIMENSION_MISMATCH, "dot2: mask dimensions");
+    return dot_sparse_dense<1>(C, M, Mask_comp, Mask_struct, A, B, c, rep);
+}
+gba_info dot4(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep) {
+    if (c.add == GBA_ANY) return GBA_NO_VALUE;      // like the CPU (Source/GB_AxB_dot4.c): ANY is not an accumulator
+    return dot_sparse_dense<0>(C, nullptr, false, false, A, B, c, rep);
+}
+
+// ------------------------------------------------------------ saxpy4/saxbit --
+// C(i,j) (+)= A(i,k) (x) B(k,j): A sparse (vector k lists i), B dense.
+// MODE 0: saxpy4, C full.  MODE 1: saxbit, C bitmap with Cx pre-set to the
+// monoid identity and Cb raised by any contributing product.
+template <class S, int MODE>
+__global__ void __launch_bounds__(256)
+saxpy_sd_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                const void *__restrict__ Ax_, bool A_iso, DenseView B, MaskViewD M, int lpr,
+                typename S::acc_t *__restrict__ Cx, int8_t *__restrict__ Cb, int64_t cvlen) {
+    using X = typename S::x_t; using Z = typename S::z_t;
+    const X *Ax = reinterpret_cast<const X *>(Ax_);
+    const X *Bx = reinterpret_cast<const X *>(B.x);
+    const int64_t j = blockIdx.y;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t k = gid / lpr;
+    const int lane = (int)(gid - k * lpr);
+    if (k >= nvecA) return;
+    const int64_t pB = j * B.vlen + k;
+    if (B.b && !B.b[pB]) return;
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    const X b = load_x<X>(Bx, pB, B.iso, bpat);
+    const int64_t pA1 = Ap[k + 1];
+    const int64_t coff = j * cvlen;
+    for (int64_t p = Ap[k] + lane; p < pA1; p += lpr) {
+        const int64_t i = Ai[p];
+        if (MODE == 1 && !maskd_allows(M, i, j)) continue;
+        const X a = load_x<X>(Ax, p, A_iso, apat);
+        const Z t = sr.mult(a, b, i, k, j);
+        sr.atomic(&Cx[coff + i], t);
+        if (MODE == 1) Cb[coff + i] = 1;
+    }
+}
+
+// widen / narrow between the stored type and the accumulator type (8/16-bit and bool)
+template <class Z, class ACC>
+__global__ void widen_kernel(const Z *__restrict__ in, ACC *__restrict__ out, int64_t n) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx < n; idx += stride) out[idx] = (ACC)in[idx];
+}
+template <class Z, class ACC>
+__global__ void narrow_kernel(const ACC *__restrict__ in, Z *__restrict__ out, int64_t n) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx < n; idx += stride) out[idx] = (Z)in[idx];
+}
+template <class ACC>
+__global__ void fill_kernel(ACC *p, int64_t n, ACC v) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx < n; idx += stride) p[idx] = v;
+}
+static unsigned grid_for(int64_t n) { int64_t b = ceil_div(n, 256); if (b > 8192) b = 8192; if (b < 1) b = 1; return (unsigned)b; }
+
+template <int MODE>
+static gba_info saxpy_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
+                                   const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep) {
+    GBA_OK(require_init());
+    if (!is_sparse(A) || !is_dense_fmt(B))
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "%s on device: A must be sparse and B bitmap/full (got %d, %d)",
+                 MODE == 0 ? "saxpy4" : "saxbit", A->sparsity, B->sparsity);
+    if (A->vdim != B->vlen) GBA_FAIL(GBA_DIMENSION_MISMATCH, "saxpy: A->vdim %ld != B->vlen %ld", (long)A->vdim, (long)B->vlen);
+    if (A->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "saxpy: A has zombies");
+    hipStream_t st = ctx().stream;
+    const int64_t cvlen = A->vlen, cvdim = B->vdim;
+    if (cvdim > 65535) GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxpy: more than 65535 dense vectors");
+    const int64_t cn = cvlen * cvdim;
+    MaskViewD mv; GBA_OK(make_maskd(M, Mask_comp, Mask_struct, &mv));
+    if (MODE == 0) {
+        if (!is_full(C) || C->type != c.ztype || C->vlen != cvlen || C->vdim != cvdim || C->iso)
+            GBA_FAIL(GBA_INVALID_VALUE, "saxpy4: C must be a full non-iso matrix of the monoid type, %ld-by-%ld", (long)cvlen, (long)cvdim);
+    }
+    const int lpr = pick_group(A);
+    DenseView Bv{B->x, is_bitmap(B) ? B->b : nullptr, B->vlen, B->iso};
+    DevBuf Cb, Cx;
+    const size_t zsize = type_size(c.ztype);
+    if (MODE == 1) {
+        GBA_OK(Cb.alloc((size_t)(cn > 0 ? cn : 1)));
+        GBA_OK(Cx.alloc((size_t)(cn > 0 ? cn : 1) * zsize));
+        GBA_HIP(hipMemsetAsync(Cb.p, 0, (size_t)(cn > 0 ? cn : 1), st));
+    }
+    KernelTimer timer(rep != nullptr);
+    if (cn > 0) {
+        GBA_OK(with_semiring(c, [&](auto sr) -> gba_info {
+            using S = decltype(sr); using Z = typename S::z_t; using ACC = typename S::acc_t;
+            Z *cx = reinterpret_cast<Z *>(MODE == 0 ? C->x : Cx.p);
+            ACC *acc = reinterpret_cast<ACC *>(cx);
+            DevBuf wide;
+            constexpr bool WIDEN = !std::is_same<Z, ACC>::value;
+            if (WIDEN) {
+                GBA_OK(wide.alloc((size_t)cn * sizeof(ACC)));
+                acc = wide.as<ACC>();
+                if (MODE == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(widen_kernel<Z, ACC>), dim3(grid_for(cn)), dim3(256), 0, st, cx, acc, cn);
+            }
+            if (MODE == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(fill_kernel<ACC>), dim3(grid_for(cn)), dim3(256), 0, st, acc, cn, (ACC)sr.identity());
+            dim3 grid((unsigned)ceil_div(A->nvec * lpr, 256), (unsigned)cvdim);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(saxpy_sd_kernel<S, MODE>), grid, dim3(256), 0, st, sr, A->nvec, A->p, A->i,
+                               A->x, A->iso, Bv, mv, lpr, acc, Cb.as<int8_t>(), cvlen);
+            if (WIDEN) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(narrow_kernel<Z, ACC>), dim3(grid_for(cn)), dim3(256), 0, st, acc, cx, cn);
+                GBA_HIP(hipStreamSynchronize(st));
+            }
+            GBA_HIP(hipGetLastError());
+            return GBA_SUCCESS;
+        }));
+    }
+    if (rep) rep->kernel_ms = timer.stop_ms();
+    if (MODE == 1) {
+        int64_t nvals = 0;
+        GBA_OK(count_ones(Cb.as<int8_t>(), cn, &nvals));
+        C->vlen = cvlen; C->vdim = cvdim; C->nvec = cvdim; C->nvals = nvals;
+        C->p = nullptr; C->h = nullptr; C->i = nullptr;
+        C->b = Cb.as<int8_t>(); Cb.release();
+        C->x = Cx.release();
+        C->nzombies = 0; C->type = c.ztype; C->sparsity = GBA_BITMAP; C->mem = GBA_MEM_DEVICE;
+        C->iso = false; C->jumbled = false;
+    } else {
+        GBA_HIP(hipStreamSynchronize(st));
+    }
+    return GBA_SUCCESS;
+}
+
+gba_info saxpy4(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep) {
+    if (c.add == GBA_ANY) return GBA_NO_VALUE;      // Source/GB_AxB_saxpy4.c: the ANY monoid is declined
+    return saxpy_sparse_dense<0>(C, nullptr, false, false, A, B, c, rep);
+}
+
+// ---------------------------------------------------------- dense x dense --
+// saxbit with both operands dense: one thread per C(i,j), k runs over the inner dimension
+template <class S>
+__global__ void __launch_bounds__(256)
+saxbit_dd_kernel(S sr, DenseView A, DenseView B, MaskViewD M, int64_t cvlen, int64_t cvdim, int64_t inner,
+                 typename S::z_t *__restrict__ Cx, int8_t *__restrict__ Cb) {
+    using X = typename S::x_t; using Z = typename S::z_t;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cvlen * cvdim) return;
+    const int64_t j = idx / cvlen, i = idx - j * cvlen;
+    if (!maskd_allows(M, i, j)) { Cb[idx] = 0; return; }
+    const X *Ax = reinterpret_cast<const X *>(A.x);
+    const X *Bx = reinterpret_cast<const X *>(B.x);
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    Z acc = sr.identity(); int found = 0;
+    for (int64_t k = 0; k < inner; k++) {
+        const int64_t pA = k * A.vlen + i, pB = j * B.vlen + k;
+        if (A.b && !A.b[pA]) continue;
+        if (B.b && !B.b[pB]) continue;
+        const Z t = sr.mult(load_x<X>(Ax, pA, A.iso, apat), load_x<X>(Bx, pB, B.iso, bpat), i, k, j);
+        acc = found ? sr.add(acc, t) : t; found = 1;
+    }
+    Cb[idx] = (int8_t)found;
+    if (found) Cx[idx] = acc;
+}
+
+gba_info saxbit(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
+                const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep) {
+    GBA_OK(require_init());
+    if (M && (M->vlen != A->vlen || M->vdim != B->vdim)) GBA_FAIL(GBA_DIMENSION_MISMATCH, "saxbit: mask dimensions");
+    if (is_sparse(A) && is_dense_fmt(B)) return saxpy_sparse_dense<1>(C, M, Mask_comp, Mask_struct, A, B, c, rep);
+    if (is_dense_fmt(A) && is_dense_fmt(B)) {
+        if (A->vdim != B->vlen) GBA_FAIL(GBA_DIMENSION_MISMATCH, "saxbit: inner dimensions");
+        hipStream_t st = ctx().stream;
+        const int64_t cvlen = A->vlen, cvdim = B->vdim, cn = cvlen * cvdim;
+        MaskViewD mv; GBA_OK(make_maskd(M, Mask_comp, Mask_struct, &mv));
+        DevBuf Cb, Cx;
+        GBA_OK(Cb.alloc((size_t)(cn > 0 ? cn : 1)));
+        GBA_OK(Cx.alloc((size_t)(cn > 0 ? cn : 1) * type_size(c.ztype)));
+        KernelTimer timer(rep != nullptr);
+        if (cn > 0) {
+            DenseView Av{A->x, is_bitmap(A) ? A->b : nullptr, A->vlen, A->iso};
+            DenseView Bv{B->x, is_bitmap(B) ? B->b : nullptr, B->vlen, B->iso};
+            GBA_OK(with_semiring(c, [&](auto sr) -> gba_info {
+                using S = decltype(sr); using Z = typename S::z_t;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(saxbit_dd_kernel<S>), dim3((unsigned)ceil_div(cn, 256)), dim3(256), 0, st,
+                                   sr, Av, Bv, mv, cvlen, cvdim, A->vdim, Cx.as<Z>(), Cb.as<int8_t>());
+                GBA_HIP(hipGetLastError());
+                return GBA_SUCCESS;
+            }));
+        }
+        if (rep) rep->kernel_ms = timer.stop_ms();
+        int64_t nvals = 0;
+        GBA_OK(count_ones(Cb.as<int8_t>(), cn, &nvals));
+        C->vlen = cvlen; C->vdim = cvdim; C->nvec = cvdim; C->nvals = nvals;
+        C->p = nullptr; C->h = nullptr; C->i = nullptr;
+        C->b = Cb.as<int8_t>(); Cb.release();
+        C->x = Cx.release();
+        C->nzombies = 0; C->type = c.ztype; C->sparsity = GBA_BITMAP; C->mem = GBA_MEM_DEVICE;
+        C->iso = false; C->jumbled = false;
+        return GBA_SUCCESS;
+    }
+    GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxbit on device: A sparse or dense, B dense (got %d, %d)", A->sparsity, B->sparsity);
+}
+
+// ------------------------------------------------------------------ saxpy5 --
+// C(:,j) += sum_k A(:,k) (x) B(k,j): A dense (column k contiguous), B sparse.
+// One thread per row i of a column tile; the column of B is walked by all
+// threads together, so A is read coalesced and nothing is atomic
+// (Source/Template/GB_AxB_saxpy5_unrolled.c:58-140 keeps 16-row register panels).
+template <class S>
+__global__ void __launch_bounds__(256)
+saxpy5_kernel(S sr, DenseView A, const int64_t *__restrict__ Bp, const int64_t *__restrict__ Bi,
+              const void *__restrict__ Bx_, bool B_iso, int64_t cvlen, typename S::z_t *__restrict__ Cx) {
+    using X = typename S::x_t; using Z = typename S::z_t;
+    const X *Ax = reinterpret_cast<const X *>(A.x);
+    const X *Bx = reinterpret_cast<const X *>(Bx_);
+    const int64_t j = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cvlen) return;
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    const int64_t pB1 = Bp[j + 1];
+    Z acc = Cx[j * cvlen + i];
+    for (int64_t pB = Bp[j]; pB < pB1; pB++) {
+        const int64_t k = Bi[pB];
+        const int64_t pA = k * A.vlen + i;
+        if (A.b && !A.b[pA]) continue;
+        const Z t = sr.mult(load_x<X>(Ax, pA, A.iso, apat), load_x<X>(Bx, pB, B_iso, bpat), i, k, j);
+        acc = sr.add(acc, t);
+    }
+    Cx[j * cvlen + i] = acc;
+}
+
+gba_info saxpy5(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep) {
+    GBA_OK(require_init());
+    if (c.add == GBA_ANY) return GBA_NO_VALUE;
+    if (!is_dense_fmt(A) || !is_sparse(B)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxpy5 on device: A bitmap/full, B sparse");
+    if (A->vdim != B->vlen) GBA_FAIL(GBA_DIMENSION_MISMATCH, "saxpy5: inner dimensions");
+    const int64_t cvlen = A->vlen, cvdim = B->vdim;
+    if (!is_full(C) || C->type != c.ztype || C->vlen != cvlen || C->vdim != cvdim || C->iso)
+        GBA_FAIL(GBA_INVALID_VALUE, "saxpy5: C must be a full non-iso matrix of the monoid type");
+    if (cvdim > 65535) GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxpy5: more than 65535 vectors in B");
+    hipStream_t st = ctx().stream;
+    KernelTimer timer(rep != nullptr);
+    if (cvlen > 0 && cvdim > 0) {
+        DenseView Av{A->x, is_bitmap(A) ? A->b : nullptr, A->vlen, A->iso};
+        GBA_OK(with_semiring(c, [&](auto sr) -> gba_info {
+            using S = decltype(sr); using Z = typename S::z_t;
+            dim3 grid((unsigned)ceil_div(cvlen, 256), (unsigned)cvdim);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(saxpy5_kernel<S>), grid, dim3(256), 0, st, sr, Av, B->p, B->i, B->x, B->iso,
+                               cvlen, reinterpret_cast<Z *>(C->x));
+            GBA_HIP(hipGetLastError());
+            return GBA_SUCCESS;
+        }));
+    }
+    if (rep) rep->kernel_ms = timer.stop_ms();
+    GBA_HIP(hipStreamSynchronize(st));
+    return GBA_SUCCESS;
+}
+
+}  // namespace gba

@@ -1,0 +1,294 @@
+// C<M> = A'*B with M sparse and not complemented: the device counterpart of
+// GB_AxB_dot3 (Source/GB_AxB_dot3.c:37) and its kernel bodies
+// Source/Template/GB_AxB_dot3_template.c:16-168 and GB_AxB_dot_cij.c:543-679.
+//
+// C takes the pattern of M.  Every mask entry M(i,j) is one dot product
+// A(:,i)'B(:,j); an entry whose dot product has no term becomes a zombie
+// (index replaced by GBA_FLIP(i), Source/Template/GB_AxB_dot3_template.c:159-164).
+// The CPU estimates the work of every entry (1 + min(ainz,bjnz), phase 1,
+// Source/Template/GB_AxB_dot3_phase1_template.c:97-125) and slices it over
+// threads.  On the GPU the same estimate routes an entry either to one thread
+// (short lists: the CPU's three-way merge / gallop) or to a whole wavefront
+// (long lists: 64 lanes stride the shorter list and binary-search the longer
+// one, results combined with shuffles).
+#include "gba_internal.hpp"
+
+namespace gba {
+
+struct OperandView {            // sparse (kind 1) or bitmap (2) / full (3)
+    int kind; const int64_t *p; const int64_t *i; const void *x; const int8_t *b; int64_t vlen; bool iso;
+};
+static OperandView make_operand(const gba_matrix *A) {
+    OperandView v{};
+    v.kind = is_sparse(A) ? 1 : (is_bitmap(A) ? 2 : 3);
+    v.p = A->p; v.i = A->i; v.x = A->x; v.b = is_bitmap(A) ? A->b : nullptr; v.vlen = A->vlen; v.iso = A->iso;
+    return v;
+}
+
+struct Dot3Mask { const int64_t *p; const int64_t *i; const uint8_t *x; int msize; bool structural, iso; };
+
+__device__ inline bool dot3_mask_value(const Dot3Mask &m, int64_t p) {
+    if (m.structural) return true;
+    const uint8_t *v = m.x + (m.iso ? 0 : p * m.msize);
+    bool nz = false;
+    for (int q = 0; q < m.msize; q++) nz |= (v[q] != 0);
+    return nz;
+}
+
+// vector id of every mask entry (the CPU gets it from its task slicing)
+__global__ void __launch_bounds__(256)
+expand_vectors_kernel(int64_t nvec, const int64_t *__restrict__ Mp, int64_t *__restrict__ Jof) {
+    const int lane = threadIdx.x & 63;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; j < nvec; j += stride) {
+        const int64_t p1 = Mp[j + 1];
+        for (int64_t p = Mp[j] + lane; p < p1; p += 64) Jof[p] = j;
+    }
+}
+
+template <class S>
+__device__ inline typename S::z_t dot_term(const S &sr, const OperandView &A, const OperandView &B, bool apat, bool bpat,
+                                           int64_t i, int64_t k, int64_t j, int64_t pA, int64_t pB) {
+    using X = typename S::x_t;
+    const X a = load_x<X>(reinterpret_cast<const X *>(A.x), pA, A.iso, apat);
+    const X b = load_x<X>(reinterpret_cast<const X *>(B.x), pB, B.iso, bpat);
+    return sr.mult(a, b, i, k, j);
+}
+
+// first position in [lo,hi] whose index is >= target (GB_TRIM_BINARY_SEARCH)
+__device__ inline int64_t lower_bound(const int64_t *__restrict__ X, int64_t lo, int64_t hi, int64_t target) {
+    while (lo <= hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (X[mid] < target) lo = mid + 1; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// one thread, whole dot product; follows Source/Template/GB_AxB_dot_cij.c
+template <class S>
+__device__ inline void dot_serial(const S &sr, const OperandView &A, const OperandView &B, int64_t i, int64_t j,
+                                  typename S::z_t &cij, int &found) {
+    using Z = typename S::z_t;
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    const bool any = sr.add_is_any();
+    found = 0; cij = sr.identity();
+    auto term = [&](int64_t k, int64_t pA, int64_t pB) {
+        const Z t = dot_term(sr, A, B, apat, bpat, i, k, j, pA, pB);
+        cij = found ? sr.add(cij, t) : t; found = 1;
+    };
+    if (A.kind == 1 && B.kind == 1) {
+        int64_t pA = A.p[i], pA_end = A.p[i + 1], pB = B.p[j], pB_end = B.p[j + 1];
+        const int64_t ainz = pA_end - pA, bjnz = pB_end - pB;
+        if (ainz == 0 || bjnz == 0) return;
+        if (A.i[pA_end - 1] < B.i[pB] || B.i[pB_end - 1] < A.i[pA]) return;     // no overlap (dot_cij.c:555)
+        if (ainz > 8 * bjnz) {                                                   // gallop in A (dot_cij.c:565-603)
+            while (pA < pA_end && pB < pB_end) {
+                const int64_t ia = A.i[pA], ib = B.i[pB];
+                if (ia < ib) pA = lower_bound(A.i, pA + 1, pA_end - 1, ib);
+                else if (ib < ia) pB++;
+                else { term(ia, pA, pB); if (any) return; pA++; pB++; }
+            }
+        } else if (bjnz > 8 * ainz) {                                            // gallop in B (dot_cij.c:605-643)
+            while (pA < pA_end && pB < pB_end) {
+                const int64_t ia = A.i[pA], ib = B.i[pB];
+                if (ia < ib) pA++;
+                else if (ib < ia) pB = lower_bound(B.i, pB + 1, pB_end - 1, ia);
+                else { term(ia, pA, pB); if (any) return; pA++; pB++; }
+            }
+        } else {                                                                 // two-pointer merge (dot_cij.c:645-678)
+            while (pA < pA_end && pB < pB_end) {
+                const int64_t ia = A.i[pA], ib = B.i[pB];
+                if (ia < ib) pA++;
+                else if (ib < ia) pB++;
+                else { term(ia, pA, pB); if (any) return; pA++; pB++; }
+            }
+        }
+    } else if (A.kind == 1) {                                                    // A sparse, B dense
+        const int64_t pA_end = A.p[i + 1], boff = j * B.vlen;
+        for (int64_t pA = A.p[i]; pA < pA_end; pA++) {
+            const int64_t k = A.i[pA];
+            if (B.b && !B.b[boff + k]) continue;
+            term(k, pA, boff + k); if (any) return;
+        }
+    } else if (B.kind == 1) {                                                    // A dense, B sparse
+        const int64_t pB_end = B.p[j + 1], aoff = i * A.vlen;
+        for (int64_t pB = B.p[j]; pB < pB_end; pB++) {
+            const int64_t k = B.i[pB];
+            if (A.b && !A.b[aoff + k]) continue;
+            term(k, aoff + k, pB); if (any) return;
+        }
+    } else {                                                                     // both dense
+        const int64_t aoff = i * A.vlen, boff = j * B.vlen;
+        for (int64_t k = 0; k < A.vlen; k++) {
+            if (A.b && !A.b[aoff + k]) continue;
+            if (B.b && !B.b[boff + k]) continue;
+            term(k, aoff + k, boff + k); if (any) return;
+        }
+    }
+}
+
+__device__ inline int64_t list_len(const OperandView &V, int64_t v) {
+    return (V.kind == 1) ? (V.p[v + 1] - V.p[v]) : V.vlen;
+}
+
+template <class S>
+__global__ void __launch_bounds__(256)
+dot3_thread_kernel(S sr, int64_t mnz, Dot3Mask M, const int64_t *__restrict__ Jof, OperandView A, OperandView B,
+                   int64_t long_work, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx,
+                   unsigned long long *__restrict__ nzombies, unsigned int *__restrict__ nlong,
+                   int64_t *__restrict__ long_list) {
+    using Z = typename S::z_t;
+    const int64_t pC = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int zombie = 0;
+    if (pC < mnz) {
+        const int64_t i = M.i[pC], j = Jof[pC];
+        if (!dot3_mask_value(M, pC)) {
+            Ci[pC] = GBA_FLIP(i); zombie = 1;
+        } else {
+            const int64_t ainz = list_len(A, i), bjnz = list_len(B, j);
+            const int64_t work = (A.kind == 1 && B.kind == 1) ? (ainz < bjnz ? ainz : bjnz) * 4 + 1
+                                                              : (ainz < bjnz ? ainz : bjnz);
+            if (work > long_work) {
+                const unsigned int q = atomicAdd(nlong, 1u);
+                long_list[q] = pC;
+            } else {
+                Z cij; int found;
+                dot_serial(sr, A, B, i, j, cij, found);
+                if (found) { Ci[pC] = i; Cx[pC] = cij; }
+                else { Ci[pC] = GBA_FLIP(i); zombie = 1; }
+            }
+        }
+    }
+    unsigned long long z = (unsigned long long)zombie;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) z += __shfl_down(z, d, 64);
+    if ((threadIdx.x & 63) == 0 && z) atomicAdd(nzombies, z);
+}
+
+// one wavefront per long dot product
+template <class S>
+__global__ void __launch_bounds__(256)
+dot3_wave_kernel(S sr, Dot3Mask M, const int64_t *__restrict__ Jof, OperandView A, OperandView B,
+                 int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx,
+                 unsigned long long *__restrict__ nzombies, const unsigned int *__restrict__ nlong,
+                 const int64_t *__restrict__ long_list) {
+    using Z = typename S::z_t;
+    const int lane = threadIdx.x & 63;
+    const unsigned int n = *nlong;
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    unsigned int q = (unsigned int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const unsigned int stride = (unsigned int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+    for (; q < n; q += stride) {
+        const int64_t pC = long_list[q];
+        const int64_t i = M.i[pC], j = Jof[pC];
+        Z cij = sr.identity(); int found = 0;
+        auto term = [&](int64_t k, int64_t pA, int64_t pB) {
+            const Z t = dot_term(sr, A, B, apat, bpat, i, k, j, pA, pB);
+            cij = found ? sr.add(cij, t) : t; found = 1;
+        };
+        if (A.kind == 1 && B.kind == 1) {
+            const int64_t pA0 = A.p[i], pA1 = A.p[i + 1], pB0 = B.p[j], pB1 = B.p[j + 1];
+            if (pA1 - pA0 <= pB1 - pB0) {           // stride A(:,i), search B(:,j)
+                for (int64_t pA = pA0 + lane; pA < pA1; pA += 64) {
+                    const int64_t k = A.i[pA];
+                    const int64_t pB = lower_bound(B.i, pB0, pB1 - 1, k);
+                    if (pB < pB1 && B.i[pB] == k) term(k, pA, pB);
+                }
+            } else {
+                for (int64_t pB = pB0 + lane; pB < pB1; pB += 64) {
+                    const int64_t k = B.i[pB];
+                    const int64_t pA = lower_bound(A.i, pA0, pA1 - 1, k);
+                    if (pA < pA1 && A.i[pA] == k) term(k, pA, pB);
+                }
+            }
+        } else if (A.kind == 1) {
+            const int64_t pA1 = A.p[i + 1], boff = j * B.vlen;
+            for (int64_t pA = A.p[i] + lane; pA < pA1; pA += 64) {
+                const int64_t k = A.i[pA];
+                if (B.b && !B.b[boff + k]) continue;
+                term(k, pA, boff + k);
+            }
+        } else if (B.kind == 1) {
+            const int64_t pB1 = B.p[j + 1], aoff = i * A.vlen;
+            for (int64_t pB = B.p[j] + lane; pB < pB1; pB += 64) {
+                const int64_t k = B.i[pB];
+                if (A.b && !A.b[aoff + k]) continue;
+                term(k, aoff + k, pB);
+            }
+        } else {
+            const int64_t aoff = i * A.vlen, boff = j * B.vlen;
+            for (int64_t k = lane; k < A.vlen; k += 64) {
+                if (A.b && !A.b[aoff + k]) continue;
+                if (B.b && !B.b[boff + k]) continue;
+                term(k, aoff + k, boff + k);
+            }
+        }
+        group_reduce(sr, cij, found, 64);
+        if (lane == 0) {
+            if (found) { Ci[pC] = i; Cx[pC] = cij; }
+            else { Ci[pC] = GBA_FLIP(i); atomicAdd(nzombies, 1ull); }
+        }
+    }
+}
+
+gba_info dot3(gba_matrix *C, const gba_matrix *M, bool Mask_struct, const gba_matrix *A,
+              const gba_matrix *B, const Canon &c, gba_report *rep) {
+    GBA_OK(require_init());
+    if (!M || !is_sparse(M)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "dot3 on device needs a sparse mask");
+    if (is_hyper(A) || is_hyper(B)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "dot3 on device: hypersparse operand");
+    if ((is_sparse(A) && A->jumbled) || (is_sparse(B) && B->jumbled))
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "dot3: operands must not be jumbled (wait on them first, Source/GB_AxB_dot.c:78-87)");
+    if (A->nzombies || B->nzombies || M->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "dot3: zombies in an input");
+    if (A->vlen != B->vlen) GBA_FAIL(GBA_DIMENSION_MISMATCH, "dot3: A->vlen %ld != B->vlen %ld", (long)A->vlen, (long)B->vlen);
+    if (M->vlen != A->vdim || M->vdim != B->vdim) GBA_FAIL(GBA_DIMENSION_MISMATCH, "dot3: mask is %ld-by-%ld, need %ld-by-%ld",
+                                                           (long)M->vlen, (long)M->vdim, (long)A->vdim, (long)B->vdim);
+    hipStream_t st = ctx().stream;
+    const int64_t mnz = M->nvals, nvec = M->nvec;
+    const size_t zsize = type_size(c.ztype);
+    DevBuf Cp, Ci, Cx, Jof, cnt, long_list;
+    GBA_OK(Cp.alloc((size_t)(nvec + 1) * 8));
+    GBA_OK(Ci.alloc((size_t)(mnz > 0 ? mnz : 1) * 8));
+    GBA_OK(Cx.alloc((size_t)(mnz > 0 ? mnz : 1) * zsize));
+    GBA_OK(Jof.alloc((size_t)(mnz > 0 ? mnz : 1) * 8));
+    GBA_OK(long_list.alloc((size_t)(mnz > 0 ? mnz : 1) * 8));
+    GBA_OK(cnt.alloc(16));
+    GBA_HIP(hipMemsetAsync(cnt.p, 0, 16, st));
+    GBA_HIP(hipMemcpyAsync(Cp.p, M->p, (size_t)(nvec + 1) * 8, hipMemcpyDeviceToDevice, st));
+    Dot3Mask mv{M->p, M->i, reinterpret_cast<const uint8_t *>(M->x), (int)type_size(M->type), Mask_struct, M->iso};
+    if (!Mask_struct && (!M->x || mv.msize == 0)) GBA_FAIL(GBA_INVALID_OBJECT, "dot3: valued mask without values");
+    unsigned long long *nzomb = cnt.as<unsigned long long>();
+    unsigned int *nlong = reinterpret_cast<unsigned int *>(cnt.as<unsigned long long>() + 1);
+    KernelTimer timer(rep != nullptr);
+    if (mnz > 0) {
+        int64_t eb = ceil_div(nvec * 64, 256); if (eb > 8192) eb = 8192;
+        hipLaunchKernelGGL(expand_vectors_kernel, dim3((unsigned)eb), dim3(256), 0, st, nvec, M->p, Jof.as<int64_t>());
+        OperandView Av = make_operand(A), Bv = make_operand(B);
+        GBA_OK(with_semiring(c, [&](auto sr) -> gba_info {
+            using S = decltype(sr); using Z = typename S::z_t;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(dot3_thread_kernel<S>), dim3((unsigned)ceil_div(mnz, 256)), dim3(256), 0, st,
+                               sr, mnz, mv, Jof.as<int64_t>(), Av, Bv, (int64_t)256, Ci.as<int64_t>(), Cx.as<Z>(),
+                               nzomb, nlong, long_list.as<int64_t>());
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(dot3_wave_kernel<S>), dim3(2048), dim3(256), 0, st,
+                               sr, mv, Jof.as<int64_t>(), Av, Bv, Ci.as<int64_t>(), Cx.as<Z>(), nzomb, nlong,
+                               long_list.as<int64_t>());
+            GBA_HIP(hipGetLastError());
+            return GBA_SUCCESS;
+        }));
+    }
+    if (rep) rep->kernel_ms = timer.stop_ms();
+    int64_t nz = 0;
+    GBA_OK(dev_read_i64(cnt.as<int64_t>(), &nz));
+    C->vlen = M->vlen; C->vdim = M->vdim; C->nvec = nvec; C->nvals = mnz;
+    C->p = reinterpret_cast<int64_t *>(Cp.release());
+    C->h = nullptr;
+    C->i = reinterpret_cast<int64_t *>(Ci.release());
+    C->x = Cx.release();
+    C->b = nullptr;
+    C->nzombies = nz;
+    C->type = c.ztype; C->sparsity = GBA_SPARSE; C->mem = GBA_MEM_DEVICE;
+    C->iso = false; C->jumbled = M->jumbled;
+    return GBA_SUCCESS;
+}
+
+}  // namespace gba

@@ -1,0 +1,839 @@
+// Front end and method selection: the device counterparts of
+//   GrB_mxm / GrB_mxv / GrB_vxm   (Source/GrB_mxm.c:18, GrB_mxv.c:18, GrB_vxm.c:19)
+//   GB_mxm                        (Source/GB_mxm.c:24)
+//   GB_AxB_meta                   (Source/GB_AxB_meta.c:41)
+//   GB_AxB_meta_adotb_control     (Source/GB_AxB_meta_adotb_control.c:12)
+//   GB_AxB_dot2_control           (Source/GB_AxB_dot2_control.c:15)
+//   GB_AxB_saxpy + _sparsity      (Source/GB_AxB_saxpy.c:16, GB_AxB_saxpy_sparsity.c:21)
+//   GB_AxB_dot                    (Source/GB_AxB_dot.c:47)
+//   GB_AxB_iso (decision only)    (Source/GB_AxB_iso.c:79)
+// Decisions are taken from the same scalars the CPU uses (formats, nnz,
+// dimensions, nvec_nonempty, diagonal test) so that the same user call lands
+// on the corresponding device method.  Two deliberate differences:
+//   * rowscale/colscale are detected and reported, then run through the saxpy
+//     kernels (each C entry is a single product, so the values are identical);
+//   * the write-back C<M> = accum(C,T) (Source/GB_accum_mask.c) exists on the
+//     device for the transplant case and for bitmap/full C; a sparse C that
+//     needs a merge with T is declined with GBA_NOT_IMPLEMENTED.
+#include "gba_internal.hpp"
+#include <cmath>
+
+namespace gba {
+
+enum { USE_ROWSCALE = 0, USE_COLSCALE = 1, USE_DOT = 2, USE_SAXPY = 3 };   // Source/GB_mxm.h:297-300
+
+struct Call {
+    gba_matrix *C;
+    const gba_matrix *M;
+    bool C_replace, Mask_comp, Mask_struct;
+    bool has_accum; gba_binop accum;
+    gba_semiring semiring;
+    const gba_matrix *A_in, *B_in;
+    bool A_transpose, B_transpose, flipxy;
+    int AxB_method, do_sort;
+};
+
+static bool any_aliased(const gba_matrix *X, const gba_matrix *Y) {
+    if (!X || !Y) return false;
+    auto eq = [](const void *a, const void *b) { return a && a == b; };
+    return eq(X->p, Y->p) || eq(X->i, Y->i) || eq(X->x, Y->x) || eq(X->b, Y->b) || eq(X->h, Y->h);
+}
+
+// GB_AxB_iso (Source/GB_AxB_iso.c:79-323), decision only
+static bool axb_iso(const gba_matrix *A, const gba_matrix *B, const gba_semiring &s, bool flipxy) {
+    int mult = s.mult, add = s.add;
+    if (op_is_positional(mult)) return false;
+    if (s.ztype == GBA_BOOL) { if (add == GBA_MIN || add == GBA_TIMES) add = GBA_LAND; else if (add == GBA_MAX || add == GBA_PLUS) add = GBA_LOR; }
+    if (s.xtype == GBA_BOOL) mult = boolean_rename(mult);
+    const bool nice = add == GBA_ANY || add == GBA_LAND || add == GBA_LOR || add == GBA_BAND || add == GBA_BOR ||
+                      add == GBA_MAX || add == GBA_MIN;
+    const bool nice_pair = nice || add == GBA_EQ || add == GBA_TIMES;
+    const bool first = (mult == GBA_ANY) || (mult == (flipxy ? GBA_SECOND : GBA_FIRST));
+    const bool second = (mult == GBA_ANY) || (mult == (flipxy ? GBA_FIRST : GBA_SECOND));
+    const bool A_iso = A->iso || (nnz_held(A) == 1 && !is_bitmap(A));
+    const bool B_iso = B->iso || (nnz_held(B) == 1 && !is_bitmap(B));
+    if (nice_pair && mult == GBA_PAIR) return true;
+    if (B_iso && nice && second) return true;
+    if (A_iso && nice && first) return true;
+    if (A_iso && B_iso) {
+        if (nice) return true;
+        if (as_if_full(A) && as_if_full(B)) return true;
+    }
+    return false;
+}
+
+static bool accum_is_monoid(const Call &k) {
+    return k.has_accum && k.accum.op == k.semiring.add && k.accum.type == k.semiring.ztype &&
+           k.C->type == k.accum.type;
+}
+
+// GB_AxB_dot4_control (Source/GB_mxm.h:207-225)
+static bool dot4_control(bool C_out_iso, const gba_matrix *C_in, const gba_matrix *M, bool Mask_comp, const Call &k) {
+    return !C_out_iso && C_in && is_full(C_in) && !M && !Mask_comp && accum_is_monoid(k);
+}
+// GB_AxB_dot3_control (Source/GB_mxm.h:233-241)
+static bool dot3_control(const gba_matrix *M, bool Mask_comp) {
+    return M && !Mask_comp && (is_sparse(M) || is_hyper(M));
+}
+
+static gba_info nvec_nonempty(const gba_matrix *A, int64_t *out) {
+    if (is_dense_fmt(A)) { *out = (A->vlen > 0) ? A->vdim : 0; return GBA_SUCCESS; }
+    if (A->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_INVALID_VALUE, "nvec_nonempty needs a device view");
+    return dev_count_nonempty(A->p, A->nvec, out);
+}
+
+// GB_AxB_dot2_control (Source/GB_AxB_dot2_control.c:15-94)
+static gba_info dot2_control(const gba_matrix *A, const gba_matrix *B, bool *use_dot2) {
+    if (is_dense_fmt(A) || is_dense_fmt(B)) { *use_dot2 = true; return GBA_SUCCESS; }
+    const double anz = (double)A->nvals, bnz = (double)B->nvals;
+    int64_t anv = 0, bnv = 0;
+    GBA_OK(nvec_nonempty(A, &anv));
+    GBA_OK(nvec_nonempty(B, &bnv));
+    const double anvec = (double)anv, bnvec = (double)bnv, avlen = (double)A->vlen;
+    const double cnz = anvec * bnvec;
+    const double row_degree = anz / (avlen > 1 ? avlen : 1);
+    const double col_degree = anz / (anvec > 1 ? anvec : 1);
+    if (cnz > anz + bnz) { *use_dot2 = false; return GBA_SUCCESS; }
+    if ((anz + bnz > 10000 * cnz) || (cnz <= 100)) { *use_dot2 = true; return GBA_SUCCESS; }
+    if (row_degree < 0.125 && col_degree > 1200) { *use_dot2 = true; return GBA_SUCCESS; }
+    *use_dot2 = false;
+    return GBA_SUCCESS;
+}
+
+static gba_info is_diagonal(const gba_matrix *A, bool *out) {
+    *out = false;
+    if (A->mem != GBA_MEM_DEVICE) return GBA_SUCCESS;
+    return dev_is_diagonal(A, out);
+}
+
+// GB_AxB_meta_adotb_control (Source/GB_AxB_meta_adotb_control.c:12-94)
+static gba_info adotb_control(int *axb_method, const Call &k, const gba_matrix *C_in, const gba_matrix *M,
+                              bool Mask_comp, const gba_matrix *A, const gba_matrix *B, bool flipxy,
+                              bool can_do_in_place, bool allow_scale, bool B_is_diagonal) {
+    *axb_method = USE_SAXPY;
+    bool A_diag = false;
+    if (allow_scale && !M && !is_bitmap(A) && B_is_diagonal) { *axb_method = USE_COLSCALE; return GBA_SUCCESS; }
+    if (allow_scale && !M && !is_bitmap(B)) { GBA_OK(is_diagonal(A, &A_diag)); if (A_diag) { *axb_method = USE_ROWSCALE; return GBA_SUCCESS; } }
+    if (k.AxB_method == GBA_DEFAULT) {
+        bool C_out_iso = false;
+        if (can_do_in_place && C_in) C_out_iso = axb_iso(A, B, k.semiring, flipxy);
+        bool d2 = false;
+        if (dot4_control(C_out_iso, can_do_in_place ? C_in : nullptr, M, Mask_comp, k)) *axb_method = USE_DOT;
+        else if (dot3_control(M, Mask_comp)) *axb_method = USE_DOT;
+        else { GBA_OK(dot2_control(A, B, &d2)); if (d2) *axb_method = USE_DOT; }
+    } else if (k.AxB_method == GBA_AxB_DOT) {
+        *axb_method = USE_DOT;
+    }
+    return GBA_SUCCESS;
+}
+
+// GB_AxB_saxpy_sparsity (Source/GB_AxB_saxpy_sparsity.c:21-246); returns true for the bitmap method
+static gba_info saxpy_sparsity(int *C_sparsity, bool *bitmap_method, const gba_matrix *M, bool Mask_comp,
+                               const gba_matrix *A, const gba_matrix *B) {
+    const bool M_sp = M && (is_sparse(M) || is_hyper(M));
+    if (M && !Mask_comp && M_sp) {
+        *C_sparsity = is_hyper(B) ? GBA_HYPERSPARSE : GBA_SPARSE;
+        *bitmap_method = false;
+        return GBA_SUCCESS;
+    }
+    const double m = (double)A->vlen, n = (double)B->vdim, anz = (double)nnz_held(A);
+    int cs = GBA_SPARSE;
+    if (is_hyper(B)) cs = GBA_HYPERSPARSE;
+    else if (is_sparse(B)) {
+        if (is_sparse(A) || is_hyper(A)) cs = GBA_SPARSE;
+        else {
+            int64_t bnv = 0;
+            GBA_OK(nvec_nonempty(B, &bnv));
+            cs = ((double)bnv < n / 4) ? GBA_SPARSE : GBA_BITMAP;
+        }
+    } else {
+        if (is_sparse(A) || is_hyper(A)) cs = (anz < m / 20) ? GBA_SPARSE : GBA_BITMAP;
+        else cs = GBA_BITMAP;
+    }
+    *C_sparsity = cs;
+    *bitmap_method = (cs == GBA_BITMAP);
+    return GBA_SUCCESS;
+}
+
+// --------------------------------------------------------- dense transpose --
+__global__ void __launch_bounds__(256)
+dense_transpose_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int64_t vlen, int64_t vdim, int esize) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= vlen * vdim) return;
+    const int64_t j = idx / vlen, i = idx - j * vlen;       // in(i,j) at j*vlen+i ; out(j,i) at i*vdim+j
+    const int64_t o = i * vdim + j;
+    for (int q = 0; q < esize; q++) out[o * esize + q] = in[idx * esize + q];
+}
+
+// T' for a bitmap/full matrix; free when one dimension is 1 (same linear order)
+static gba_info dense_transposed(const gba_matrix *A, gba_matrix *AT, std::vector<void *> &owned) {
+    *AT = *A;
+    AT->vlen = A->vdim; AT->vdim = A->vlen; AT->nvec = A->vlen;
+    if (A->vlen == 1 || A->vdim == 1) return GBA_SUCCESS;
+    hipStream_t st = ctx().stream;
+    const int64_t n = A->vlen * A->vdim;
+    const int esize = (int)type_size(A->type);
+    if (A->b) {
+        void *b = gba_malloc((size_t)n); if (!b) GBA_FAIL(GBA_OUT_OF_MEMORY, "dense transpose");
+        owned.push_back(b);
+        hipLaunchKernelGGL(dense_transpose_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const uint8_t *>(A->b), reinterpret_cast<uint8_t *>(b), A->vlen, A->vdim, 1);
+        AT->b = reinterpret_cast<int8_t *>(b);
+    }
+    if (A->x && !A->iso) {
+        void *x = gba_malloc((size_t)n * esize); if (!x) GBA_FAIL(GBA_OUT_OF_MEMORY, "dense transpose");
+        owned.push_back(x);
+        hipLaunchKernelGGL(dense_transpose_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const uint8_t *>(A->x), reinterpret_cast<uint8_t *>(x), A->vlen, A->vdim, esize);
+        AT->x = x;
+    }
+    GBA_HIP(hipGetLastError());
+    return GBA_SUCCESS;
+}
+
+// explicit transpose of an operand or mask (GB_transpose_cast)
+static gba_info transposed(const gba_matrix *A, gba_matrix *AT, std::vector<void *> &owned) {
+    if (is_dense_fmt(A)) return dense_transposed(A, AT, owned);
+    if (!is_sparse(A)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "transpose of a hypersparse matrix");
+    GBA_OK(transpose(AT, A));
+    owned.push_back(AT->p); owned.push_back(AT->i); owned.push_back(AT->x);
+    return GBA_SUCCESS;
+}
+
+// ------------------------------------------------------- dense write-back --
+struct WbMask { int kind; bool comp, structural, iso; int msize; int64_t vlen; const int64_t *p, *i; const int8_t *b; const uint8_t *x; };
+
+__device__ inline bool wb_mask(const WbMask &m, int64_t i, int64_t j) {
+    if (m.kind == 0) return !m.comp;
+    bool mij = false;
+    int64_t p = -1;
+    if (m.kind == 1) {
+        int64_t lo = m.p[j], hi = m.p[j + 1] - 1;
+        while (lo <= hi) { int64_t mid = (lo + hi) >> 1; int64_t v = m.i[mid]; if (v < i) lo = mid + 1; else if (v > i) hi = mid - 1; else { p = mid; break; } }
+        mij = (p >= 0);
+    } else {
+        p = j * m.vlen + i;
+        mij = (m.kind == 2) ? (m.b[p] != 0) : true;
+    }
+    if (mij && !m.structural) {
+        const uint8_t *v = m.x + (m.iso ? 0 : p * m.msize);
+        bool nz = false;
+        for (int q = 0; q < m.msize; q++) nz |= (v[q] != 0);
+        mij = nz;
+    }
+    return mij != m.comp;
+}
+
+// C<M> = accum (C,T) for bitmap C (GB_accum_mask semantics, Source/GB_accum_mask.c,
+// Test/GB_spec_accum_mask.m): one thread per position
+template <class Z>
+__global__ void __launch_bounds__(256)
+writeback_dense_kernel(int64_t vlen, int64_t vdim, Z *__restrict__ Cx, int8_t *__restrict__ Cb,
+                       const Z *__restrict__ Tx, const int8_t *__restrict__ Tb, bool T_iso,
+                       WbMask M, int accum_op, bool C_replace) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= vlen * vdim) return;
+    const int64_t j = p / vlen, i = p - j * vlen;
+    const bool c_in = Cb[p] != 0;
+    const bool t_in = Tb ? (Tb[p] != 0) : true;
+    if (wb_mask(M, i, j)) {
+        if (t_in) {
+            const Z t = Tx[T_iso ? 0 : p];
+            Cx[p] = (accum_op != GBA_NOP && c_in) ? mult_tt<Z>(accum_op, Cx[p], t) : t;
+            Cb[p] = 1;
+        } else if (accum_op == GBA_NOP) {
+            Cb[p] = 0;                    // Z = T has no entry here
+        }                                 // with accum: Z(i,j) = C(i,j), unchanged
+    } else if (C_replace) {
+        Cb[p] = 0;
+    }
+}
+
+template <class Z>
+__global__ void __launch_bounds__(256)
+scatter_sparse_kernel(int64_t nvec, const int64_t *__restrict__ Tp, const int64_t *__restrict__ Ti,
+                      const Z *__restrict__ Tx, bool T_iso, int64_t vlen, Z *__restrict__ Dx, int8_t *__restrict__ Db) {
+    const int lane = threadIdx.x & 63;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; j < nvec; j += stride) {
+        const int64_t p1 = Tp[j + 1];
+        for (int64_t p = Tp[j] + lane; p < p1; p += 64) {
+            const int64_t i = Ti[p];
+            if (i < 0) continue;          // zombie
+            Dx[j * vlen + i] = Tx[T_iso ? 0 : p];
+            Db[j * vlen + i] = 1;
+        }
+    }
+}
+
+template <class F>
+static gba_info with_type(int code, F &&f) {
+    switch (code) {
+        case GBA_BOOL: return f(bool());
+        case GBA_INT8: return f(int8_t());     case GBA_UINT8: return f(uint8_t());
+        case GBA_INT16: return f(int16_t());   case GBA_UINT16: return f(uint16_t());
+        case GBA_INT32: return f(int32_t());   case GBA_UINT32: return f(uint32_t());
+        case GBA_INT64: return f(int64_t());   case GBA_UINT64: return f(uint64_t());
+        case GBA_FP32: return f(float());      case GBA_FP64: return f(double());
+        default: GBA_FAIL(GBA_NOT_IMPLEMENTED, "type %d on device", code);
+    }
+}
+
+static bool accum_op_ok(int op) {
+    switch (op) {
+        case GBA_FIRST: case GBA_SECOND: case GBA_ANY: case GBA_PAIR: case GBA_MIN: case GBA_MAX: case GBA_PLUS:
+        case GBA_MINUS: case GBA_RMINUS: case GBA_TIMES: case GBA_DIV: case GBA_RDIV: case GBA_ISEQ: case GBA_ISNE:
+        case GBA_ISGT: case GBA_ISLT: case GBA_ISGE: case GBA_ISLE: case GBA_LOR: case GBA_LAND: case GBA_LXOR:
+        case GBA_BOR: case GBA_BAND: case GBA_BXOR: case GBA_BXNOR:
+            return true;
+        default: return false;
+    }
+}
+
+static gba_info make_wb_mask(const gba_matrix *M, bool comp, bool structural, WbMask *w) {
+    WbMask m{};
+    m.comp = comp;
+    if (M) {
+        if (is_hyper(M)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse mask");
+        if (is_sparse(M) && M->jumbled) GBA_FAIL(GBA_NOT_IMPLEMENTED, "jumbled mask");
+        m.kind = is_sparse(M) ? 1 : (is_bitmap(M) ? 2 : 3);
+        m.structural = structural; m.iso = M->iso; m.msize = (int)type_size(M->type); m.vlen = M->vlen;
+        m.p = M->p; m.i = M->i; m.b = M->b; m.x = reinterpret_cast<const uint8_t *>(M->x);
+    }
+    *w = m;
+    return GBA_SUCCESS;
+}
+
+// C (bitmap or full, updated in place or converted to bitmap) <M> = accum (C, T)
+static gba_info writeback_dense(const Call &k, const gba_matrix *M, gba_matrix *T) {
+    gba_matrix *C = k.C;
+    hipStream_t st = ctx().stream;
+    const int64_t n = C->vlen * C->vdim;
+    if (T->vlen != C->vlen || T->vdim != C->vdim) GBA_FAIL(GBA_PANIC, "write-back: T is %ld-by-%ld, C is %ld-by-%ld",
+                                                           (long)T->vlen, (long)T->vdim, (long)C->vlen, (long)C->vdim);
+    if (T->type != C->type) GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back with typecast (%d -> %d)", T->type, C->type);
+    if (k.has_accum && (k.accum.type != C->type || !accum_op_ok(k.accum.op)))
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "accum operator %d on type %d", k.accum.op, k.accum.type);
+    const size_t zs = type_size(C->type);
+    // C becomes bitmap for the update
+    DevBuf newb;
+    int8_t *Cb = C->b;
+    if (is_full(C)) {
+        GBA_OK(newb.alloc((size_t)(n > 0 ? n : 1)));
+        GBA_HIP(hipMemsetAsync(newb.p, 1, (size_t)(n > 0 ? n : 1), st));
+        Cb = newb.as<int8_t>();
+    }
+    void *Cx = C->x;
+    DevBuf newx;
+    if (C->iso) {
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back into an iso-valued C");
+    }
+    // dense image of T
+    DevBuf Db, Dx;
+    const int8_t *Tb = nullptr; const void *Tx = T->x; bool T_iso = T->iso;
+    if (is_sparse(T)) {
+        GBA_OK(Db.alloc((size_t)(n > 0 ? n : 1)));
+        GBA_OK(Dx.alloc((size_t)(n > 0 ? n : 1) * zs));
+        GBA_HIP(hipMemsetAsync(Db.p, 0, (size_t)(n > 0 ? n : 1), st));
+        if (T->nvals > 0) {
+            GBA_OK(with_type(C->type, [&](auto z) -> gba_info {
+                using Z = decltype(z);
+                int64_t blocks = ceil_div(T->nvec * 64, 256); if (blocks > 8192) blocks = 8192;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(scatter_sparse_kernel<Z>), dim3((unsigned)blocks), dim3(256), 0, st,
+                                   T->nvec, T->p, T->i, reinterpret_cast<const Z *>(T->x), T->iso, T->vlen,
+                                   Dx.as<Z>(), Db.as<int8_t>());
+                return GBA_SUCCESS;
+            }));
+        }
+        Tb = Db.as<int8_t>(); Tx = Dx.p; T_iso = false;
+    } else if (is_bitmap(T)) {
+        Tb = T->b;
+    } else if (!is_full(T)) {
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back of a hypersparse T");
+    }
+    WbMask wm; GBA_OK(make_wb_mask(M, k.Mask_comp, k.Mask_struct, &wm));
+    if (n > 0) {
+        GBA_OK(with_type(C->type, [&](auto z) -> gba_info {
+            using Z = decltype(z);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(writeback_dense_kernel<Z>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                               C->vlen, C->vdim, reinterpret_cast<Z *>(Cx), Cb, reinterpret_cast<const Z *>(Tx), Tb, T_iso,
+                               wm, k.has_accum ? k.accum.op : (int)GBA_NOP, k.C_replace);
+            GBA_HIP(hipGetLastError());
+            return GBA_SUCCESS;
+        }));
+    }
+    GBA_HIP(hipStreamSynchronize(st));
+    // count entries, conform: all present -> full, else bitmap
+    int64_t nvals = 0;
+    GBA_OK(dev_count_ones(Cb, n, &nvals));
+    if (nvals == n) {
+        if (is_bitmap(C)) { gba_free(C->b); }
+        C->b = nullptr; C->sparsity = GBA_FULL; C->nvals = n;
+    } else {
+        if (is_full(C)) { C->b = reinterpret_cast<int8_t *>(newb.release()); }
+        C->sparsity = GBA_BITMAP; C->nvals = nvals;
+    }
+    C->p = nullptr; C->i = nullptr; C->h = nullptr; C->nvec = C->vdim; C->jumbled = false; C->nzombies = 0;
+    return GBA_SUCCESS;
+}
+
+static void free_unaliased(gba_matrix *C, const Call &k) {
+    auto aliased = [&](const void *q) {
+        if (!q) return true;
+        const gba_matrix *ins[3] = {k.M, k.A_in, k.B_in};
+        for (const gba_matrix *X : ins) {
+            if (!X) continue;
+            if (q == X->p || q == X->i || q == X->x || q == X->b || q == X->h) return true;
+        }
+        return false;
+    };
+    if (C->mem != GBA_MEM_DEVICE) return;
+    if (!aliased(C->p)) gba_free(C->p);
+    if (!aliased(C->h)) gba_free(C->h);
+    if (!aliased(C->i)) gba_free(C->i);
+    if (!aliased(C->x)) gba_free(C->x);
+    if (!aliased(C->b)) gba_free(C->b);
+    C->p = C->h = C->i = nullptr; C->x = nullptr; C->b = nullptr;
+}
+
+// ----------------------------------------------------------------- drivers --
+struct Exec {
+    gba_report rep{};
+    bool mask_applied = false, done_in_place = false;
+    std::vector<void *> owned;          // temporaries to free at the end
+    ~Exec() { for (void *p : owned) gba_free(p); }
+};
+
+// GB_AxB_dot (Source/GB_AxB_dot.c:47-215): C = A'*B
+static gba_info run_dot(gba_matrix *T, const Call &k, const gba_matrix *C_in, const gba_matrix *M,
+                        const gba_matrix *A, const gba_matrix *B, bool flipxy, Exec &ex, bool select_only) {
+    Canon c;
+    GBA_OK(canonicalize(&k.semiring, flipxy, A->type, B->type, &c));
+    const bool C_iso = axb_iso(A, B, k.semiring, flipxy);
+    if (C_iso && A->iso && as_if_full(A) && B->iso && as_if_full(B)) ex.rep.method = GBA_METHOD_ISO_FULL;
+    if (dot4_control(C_iso, C_in, M, k.Mask_comp, k) && c.add != GBA_ANY) {
+        ex.rep.method = GBA_METHOD_DOT4;
+        if (select_only) { ex.done_in_place = true; return GBA_SUCCESS; }
+        gba_info info = dot4(k.C, A, B, c, &ex.rep);
+        if (info != GBA_NO_VALUE) { ex.done_in_place = (info == GBA_SUCCESS); return info; }
+    }
+    if (dot3_control(M, k.Mask_comp)) {
+        ex.rep.method = GBA_METHOD_DOT3;
+        ex.mask_applied = true;
+        if (select_only) return GBA_SUCCESS;
+        return dot3(T, M, k.Mask_struct, A, B, c, &ex.rep);
+    }
+    ex.rep.method = GBA_METHOD_DOT2;
+    ex.mask_applied = (M != nullptr);
+    if (select_only) return GBA_SUCCESS;
+    return dot2(T, M, k.Mask_comp, k.Mask_struct, A, B, c, &ex.rep);
+}
+
+// GB_AxB_saxpy (Source/GB_AxB_saxpy.c:16-259): C = A*B
+static gba_info run_saxpy(gba_matrix *T, const Call &k, const gba_matrix *C_in, const gba_matrix *M,
+                          const gba_matrix *A, const gba_matrix *B, bool flipxy, Exec &ex, bool select_only) {
+    Canon c;
+    GBA_OK(canonicalize(&k.semiring, flipxy, A->type, B->type, &c));
+    int C_sparsity = GBA_SPARSE; bool bitmap_method = false;
+    GBA_OK(saxpy_sparsity(&C_sparsity, &bitmap_method, M, k.Mask_comp, A, B));
+    const bool C_iso = axb_iso(A, B, k.semiring, flipxy);
+    if (C_iso && A->iso && as_if_full(A) && B->iso && as_if_full(B)) {
+        ex.rep.method = GBA_METHOD_ISO_FULL;
+        if (select_only) return GBA_SUCCESS;
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "iso full result");
+    }
+    if (!C_iso && C_in && is_full(C_in) && !M && accum_is_monoid(k)) {
+        if ((is_sparse(A) || is_hyper(A)) && is_dense_fmt(B) && c.add != GBA_ANY) {
+            ex.rep.method = GBA_METHOD_SAXPY4;
+            if (select_only) { ex.done_in_place = true; return GBA_SUCCESS; }
+            gba_info info = saxpy4(k.C, A, B, c, &ex.rep);
+            if (info != GBA_NO_VALUE) { ex.done_in_place = (info == GBA_SUCCESS); return info; }
+        } else if (is_dense_fmt(A) && (is_sparse(B) || is_hyper(B)) && c.add != GBA_ANY &&
+                   (c.a_pattern || A->type == c.xtype)) {
+            ex.rep.method = GBA_METHOD_SAXPY5;
+            if (select_only) { ex.done_in_place = true; return GBA_SUCCESS; }
+            gba_info info = saxpy5(k.C, A, B, c, &ex.rep);
+            if (info != GBA_NO_VALUE) { ex.done_in_place = (info == GBA_SUCCESS); return info; }
+        }
+    }
+    if (!bitmap_method) {
+        ex.rep.method = GBA_METHOD_SAXPY3;
+        if (select_only) { ex.mask_applied = (M != nullptr); return GBA_SUCCESS; }
+        gba_info info = saxpy3(T, M, k.Mask_comp, k.Mask_struct, A, B, c, k.AxB_method, k.do_sort, &ex.mask_applied, &ex.rep);
+        if (info == GBA_NO_VALUE) {
+            // mask discarded: redo the analysis without it (Source/GB_AxB_saxpy.c:212-225)
+            ex.mask_applied = false;
+            return run_saxpy(T, k, nullptr, nullptr, A, B, flipxy, ex, select_only);
+        }
+        return info;
+    }
+    if (is_dense_fmt(A) && (is_sparse(B) || is_hyper(B))) {
+        ex.rep.method = GBA_METHOD_DOT2;        // dot2 with A not transposed (Source/GB_AxB_saxpy.c:237-245)
+        ex.mask_applied = (M != nullptr);
+        if (select_only) return GBA_SUCCESS;
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "bitmap C = dense A * sparse B");
+    }
+    ex.rep.method = GBA_METHOD_SAXBIT;
+    ex.mask_applied = (M != nullptr);
+    if (select_only) return GBA_SUCCESS;
+    return saxbit(T, M, k.Mask_comp, k.Mask_struct, A, B, c, &ex.rep);
+}
+
+// GB_mxm + GB_AxB_meta
+static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
+    GBA_OK(require_init());
+    Exec ex;
+    ex.rep.flops = -1;
+    gba_matrix *C = k.C;
+    if (!C || !k.A_in || !k.B_in) GBA_FAIL(GBA_NULL_POINTER, "C, A or B is NULL");
+    // inputs staged from host memory if needed (PCIe); C must be a device view
+    gba_matrix Mdev, Adev, Bdev;
+    if (C->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_NOT_IMPLEMENTED, "C must be a device view (mem == GBA_MEM_DEVICE)");
+    const gba_matrix *M_user = k.M;
+    if (k.M && k.M->mem == GBA_MEM_HOST) { GBA_OK(stage_to_device(k.M, &Mdev, ex.owned)); k.M = &Mdev; }
+    if (k.A_in->mem == GBA_MEM_HOST) { GBA_OK(stage_to_device(k.A_in, &Adev, ex.owned)); k.A_in = &Adev; }
+    if (k.B_in->mem == GBA_MEM_HOST) { GBA_OK(stage_to_device(k.B_in, &Bdev, ex.owned)); k.B_in = &Bdev; }
+    (void)M_user;
+    const gba_matrix *A_in = k.A_in, *B_in = k.B_in;
+    if (is_hyper(A_in) || is_hyper(B_in) || is_hyper(C) || (k.M && is_hyper(k.M)))
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse matrices stay on the CPU path");
+    if (A_in->nzombies || B_in->nzombies || (k.M && k.M->nzombies))
+        GBA_FAIL(GBA_INVALID_OBJECT, "inputs with zombies: call gba_matrix_wait first (Source/GB_mxm.c:105-116)");
+
+    // dimensions (Source/GB_mxm.c:84-99); nrows/ncols depend on the storage orientation
+    auto nrows = [](const gba_matrix *X) { return X->is_csc ? X->vlen : X->vdim; };
+    auto ncols = [](const gba_matrix *X) { return X->is_csc ? X->vdim : X->vlen; };
+    const int64_t anrows = k.A_transpose ? ncols(A_in) : nrows(A_in), ancols = k.A_transpose ? nrows(A_in) : ncols(A_in);
+    const int64_t bnrows = k.B_transpose ? ncols(B_in) : nrows(B_in), bncols = k.B_transpose ? nrows(B_in) : ncols(B_in);
+    if (ancols != bnrows || nrows(C) != anrows || ncols(C) != bncols)
+        GBA_FAIL(GBA_DIMENSION_MISMATCH, "Dimensions not compatible: output is %ld-by-%ld, first input is %ld-by-%ld%s, second input is %ld-by-%ld%s",
+                 (long)nrows(C), (long)ncols(C), (long)anrows, (long)ancols, k.A_transpose ? " (transposed)" : "",
+                 (long)bnrows, (long)bncols, k.B_transpose ? " (transposed)" : "");
+    if (k.M && (nrows(k.M) != nrows(C) || ncols(k.M) != ncols(C)))
+        GBA_FAIL(GBA_DIMENSION_MISMATCH, "mask is %ld-by-%ld, output is %ld-by-%ld", (long)nrows(k.M), (long)ncols(k.M), (long)nrows(C), (long)ncols(C));
+    if (C->type != k.semiring.ztype) GBA_FAIL(GBA_NOT_IMPLEMENTED, "C has type %d, the monoid %d (typecast on write-back)", C->type, k.semiring.ztype);
+    if (k.has_accum && op_is_positional(k.accum.op)) GBA_FAIL(GBA_DOMAIN_MISMATCH, "positional accum");
+
+    // mask shortcuts (Source/GB_mxm.c:105-114)
+    const gba_matrix *M = k.M;
+    if (M && k.Mask_struct && as_if_full(M) && !is_bitmap(M)) M = nullptr;
+    if (!M && k.Mask_comp) {
+        // C<!NULL>: nothing can be written (GB_RETURN_IF_QUICK_MASK)
+        if (!select_only && k.C_replace) {
+            if (is_sparse(C)) { C->nvals = 0; if (C->p) GBA_HIP(hipMemsetAsync(C->p, 0, (size_t)(C->nvec + 1) * 8, ctx().stream)); }
+            else if (is_bitmap(C)) { C->nvals = 0; GBA_HIP(hipMemsetAsync(C->b, 0, (size_t)(C->vlen * C->vdim), ctx().stream)); }
+            else GBA_FAIL(GBA_NOT_IMPLEMENTED, "clearing a full C");
+        }
+        if (report) *report = ex.rep;
+        return GBA_SUCCESS;
+    }
+    k.M = M;
+
+    // ---- GB_AxB_meta ------------------------------------------------------
+    const int mult0 = k.semiring.mult;
+    const bool allow_scale = true;
+    const double A_work = (double)nnz_held(A_in), B_work = (double)nnz_held(B_in);
+    const double C_work = (double)anrows * (double)bncols;
+    bool can_do_in_place = false;
+    if (k.has_accum) {
+        can_do_in_place = is_full(C) && accum_is_monoid(k) && (!M || !k.C_replace);
+    }
+    const bool C_is_csc = C->is_csc;
+    bool C_transpose = !C_is_csc;
+    const bool M_is_csc = M ? M->is_csc : C_is_csc;
+    bool M_transpose = !M_is_csc;
+    bool A_transpose = k.A_transpose, B_transpose = k.B_transpose;
+    if (!A_in->is_csc) A_transpose = !A_transpose;
+    if (!B_in->is_csc) B_transpose = !B_transpose;
+    bool flipxy = k.flipxy;
+
+    bool swap_rule = false;
+    bool A_in_diag = false, B_in_diag = false;
+    bool A_in_diag_known = false, B_in_diag_known = false;
+    if (C_transpose && A_transpose && B_transpose) swap_rule = true;
+    else if (!C_transpose && A_transpose && B_transpose) swap_rule = true;
+    else if (C_transpose && A_transpose && !B_transpose) {
+        swap_rule = true;
+        GBA_OK(is_diagonal(A_in, &A_in_diag)); A_in_diag_known = true;
+        int tentative;
+        GBA_OK(adotb_control(&tentative, k, C, M, k.Mask_comp, B_in, A_in, flipxy, can_do_in_place, allow_scale, A_in_diag));
+        if (tentative == USE_SAXPY) swap_rule = (B_work < A_work + C_work);
+    } else if (C_transpose && !A_transpose && B_transpose) swap_rule = (A_work < B_work + C_work);
+    else if (!C_transpose && !A_transpose && B_transpose) swap_rule = (B_work > A_work + C_work);
+    else if (!C_transpose && A_transpose && !B_transpose) {
+        swap_rule = false;
+        GBA_OK(is_diagonal(B_in, &B_in_diag)); B_in_diag_known = true;
+        int tentative;
+        GBA_OK(adotb_control(&tentative, k, C, M, k.Mask_comp, A_in, B_in, flipxy, can_do_in_place, allow_scale, B_in_diag));
+        if (tentative == USE_SAXPY) swap_rule = (A_work > B_work + C_work);
+    }
+    const gba_matrix *A, *B;
+    bool atrans, btrans;
+    int A_diag = -1, B_diag = -1;
+    if (swap_rule) {
+        A = B_in; atrans = !B_transpose;
+        B = A_in; btrans = !A_transpose;
+        flipxy = !flipxy;
+        M_transpose = !M_transpose;
+        C_transpose = !C_transpose;
+        A_diag = B_in_diag_known ? (int)B_in_diag : -1;
+    } else {
+        A = A_in; atrans = A_transpose;
+        B = B_in; btrans = B_transpose;
+        B_diag = B_in_diag_known ? (int)B_in_diag : -1;
+    }
+    (void)A_in_diag_known; (void)mult0;
+    ex.rep.swapped = swap_rule;
+
+    // explicit transpose of the mask (Source/GB_AxB_meta.c:476-492)
+    gba_matrix MT;
+    const gba_matrix *Mx = M;
+    if (M_transpose && M) {
+        if (select_only) { MT = *M; MT.vlen = M->vdim; MT.vdim = M->vlen; MT.nvec = M->vlen; }
+        else GBA_OK(transposed(M, &MT, ex.owned));
+        MT.is_csc = C_is_csc;
+        Mx = &MT;
+    }
+    if (can_do_in_place) {
+        const bool aliased = any_aliased(C, Mx) || any_aliased(C, A) || any_aliased(C, B);
+        if (C_transpose || aliased) can_do_in_place = false;
+    }
+    const gba_matrix *C_in = can_do_in_place ? C : nullptr;
+
+    auto get_diag = [&](const gba_matrix *X, int &cache) -> gba_info {
+        if (cache < 0) { bool d = false; GBA_OK(is_diagonal(X, &d)); cache = d ? 1 : 0; }
+        return GBA_SUCCESS;
+    };
+
+    gba_matrix T{};          // result of the multiply when not done in place
+    T.type = k.semiring.ztype; T.mem = GBA_MEM_DEVICE;
+    gba_matrix AT, BT;
+    int axb_method = USE_SAXPY;
+    gba_info info = GBA_SUCCESS;
+    auto explicit_T = [&](const gba_matrix *X, gba_matrix *XT, int32_t *flag) -> gba_info {
+        *flag = 1;
+        if (select_only) { *XT = *X; XT->vlen = X->vdim; XT->vdim = X->vlen; XT->nvec = X->vlen; return GBA_SUCCESS; }
+        return transposed(X, XT, ex.owned);
+    };
+    if (atrans) {
+        GBA_OK(get_diag(B, B_diag));
+        if (btrans && !B_diag) { GBA_OK(explicit_T(B, &BT, &ex.rep.b_transposed)); B = &BT; }
+        GBA_OK(adotb_control(&axb_method, k, C, Mx, k.Mask_comp, A, B, flipxy, can_do_in_place, allow_scale, B_diag == 1));
+        if (axb_method == USE_COLSCALE || axb_method == USE_SAXPY) {
+            GBA_OK(explicit_T(A, &AT, &ex.rep.a_transposed));
+            if (is_bitmap(&AT)) axb_method = USE_SAXPY;
+        }
+        switch (axb_method) {
+            case USE_ROWSCALE: info = run_saxpy(&T, k, nullptr, nullptr, A, B, flipxy, ex, select_only); ex.rep.method = GBA_METHOD_ROWSCALE; break;
+            case USE_COLSCALE: info = run_saxpy(&T, k, nullptr, nullptr, &AT, B, flipxy, ex, select_only); ex.rep.method = GBA_METHOD_COLSCALE; break;
+            case USE_DOT:      info = run_dot(&T, k, C_in, Mx, A, B, flipxy, ex, select_only); break;
+            default:           info = run_saxpy(&T, k, C_in, Mx, &AT, B, flipxy, ex, select_only); break;
+        }
+    } else if (btrans) {
+        GBA_OK(get_diag(B, B_diag));
+        if (allow_scale && !Mx && !is_bitmap(A) && B_diag == 1) axb_method = USE_COLSCALE;
+        else {
+            GBA_OK(get_diag(A, A_diag));
+            if (allow_scale && !Mx && !is_bitmap(B) && A_diag == 1) axb_method = USE_ROWSCALE;
+            else if (k.AxB_method == GBA_AxB_DOT) axb_method = USE_DOT;
+        }
+        if (axb_method != USE_COLSCALE) {
+            GBA_OK(explicit_T(B, &BT, &ex.rep.b_transposed));
+            if (axb_method == USE_ROWSCALE && is_bitmap(&BT)) axb_method = USE_SAXPY;
+        }
+        switch (axb_method) {
+            case USE_COLSCALE: info = run_saxpy(&T, k, nullptr, nullptr, A, B, flipxy, ex, select_only); ex.rep.method = GBA_METHOD_COLSCALE; break;
+            case USE_ROWSCALE: info = run_saxpy(&T, k, nullptr, nullptr, A, &BT, flipxy, ex, select_only); ex.rep.method = GBA_METHOD_ROWSCALE; break;
+            case USE_DOT:
+                GBA_OK(explicit_T(A, &AT, &ex.rep.a_transposed));
+                info = run_dot(&T, k, C_in, Mx, &AT, &BT, flipxy, ex, select_only); break;
+            default: info = run_saxpy(&T, k, C_in, Mx, A, &BT, flipxy, ex, select_only); break;
+        }
+    } else {
+        GBA_OK(get_diag(B, B_diag));
+        if (allow_scale && !Mx && !is_bitmap(A) && B_diag == 1) axb_method = USE_COLSCALE;
+        else {
+            GBA_OK(get_diag(A, A_diag));
+            if (allow_scale && !Mx && !is_bitmap(B) && A_diag == 1) axb_method = USE_ROWSCALE;
+            else if (k.AxB_method == GBA_AxB_DOT) axb_method = USE_DOT;
+            else axb_method = USE_SAXPY;       // hypersparse A * dense B would pick dot; hyper is declined above
+        }
+        switch (axb_method) {
+            case USE_COLSCALE: info = run_saxpy(&T, k, nullptr, nullptr, A, B, flipxy, ex, select_only); ex.rep.method = GBA_METHOD_COLSCALE; break;
+            case USE_ROWSCALE: info = run_saxpy(&T, k, nullptr, nullptr, A, B, flipxy, ex, select_only); ex.rep.method = GBA_METHOD_ROWSCALE; break;
+            case USE_DOT:
+                GBA_OK(explicit_T(A, &AT, &ex.rep.a_transposed));
+                info = run_dot(&T, k, C_in, Mx, &AT, B, flipxy, ex, select_only); break;
+            default: info = run_saxpy(&T, k, C_in, Mx, A, B, flipxy, ex, select_only); break;
+        }
+    }
+    ex.rep.mask_applied = ex.mask_applied;
+    ex.rep.done_in_place = ex.done_in_place;
+    if (report) *report = ex.rep;
+    if (info != GBA_SUCCESS) { gba_matrix_free_content(&T); return info; }
+    if (select_only || ex.done_in_place) return GBA_SUCCESS;
+
+    // ---- back in GB_mxm: C<M> = accum (C,T) (Source/GB_mxm.c:164-221) -------
+    T.is_csc = C_transpose ? !C_is_csc : C_is_csc;
+    if (T.is_csc != C_is_csc) {
+        // T holds C'; transpose it now (GB_accum_mask does this with GB_transpose)
+        if (T.nzombies) { info = matrix_wait(&T); if (info != GBA_SUCCESS) { gba_matrix_free_content(&T); return info; } }
+        gba_matrix TT;
+        std::vector<void *> tmp;
+        info = transposed(&T, &TT, tmp);
+        if (info != GBA_SUCCESS) { gba_matrix_free_content(&T); return info; }
+        GBA_HIP(hipStreamSynchronize(ctx().stream));
+        if (is_dense_fmt(&T) && (T.vlen == 1 || T.vdim == 1)) { /* same arrays */ }
+        else gba_matrix_free_content(&T);
+        T = TT;
+        T.is_csc = C_is_csc;
+    }
+    const bool c_empty = (nnz_held(C) == 0) && !is_full(C);
+    if (!k.has_accum && (!M || ex.mask_applied) && (k.C_replace || c_empty)) {
+        // transplant (Source/GB_mxm.c:168-199)
+        free_unaliased(C, k);
+        const bool csc = C->is_csc;
+        *C = T;
+        C->is_csc = csc;
+        return GBA_SUCCESS;
+    }
+    if (is_dense_fmt(C)) {
+        info = writeback_dense(k, M, &T);
+        gba_matrix_free_content(&T);
+        return info;
+    }
+    gba_matrix_free_content(&T);
+    GBA_FAIL(GBA_NOT_IMPLEMENTED, "C<M> = accum (C,T) into a sparse C that already holds entries");
+}
+
+}  // namespace gba
+
+using namespace gba;
+
+static Call make_call(gba_matrix *C, const gba_matrix *M, const gba_binop *accum, const gba_semiring *semiring,
+                      const gba_matrix *A, bool A_tran, const gba_matrix *B, bool B_tran, bool flipxy,
+                      const gba_descriptor *d) {
+    Call k{};
+    k.C = C; k.M = M;
+    k.C_replace = d && d->out == GBA_REPLACE;
+    k.Mask_comp = d && (d->mask == GBA_COMP || d->mask == GBA_COMP_STRUCTURE);
+    k.Mask_struct = d && (d->mask == GBA_STRUCTURE || d->mask == GBA_COMP_STRUCTURE);
+    k.has_accum = accum && accum->op != GBA_NOP;
+    if (k.has_accum) k.accum = *accum;
+    if (semiring) k.semiring = *semiring;
+    k.A_in = A; k.B_in = B;
+    k.A_transpose = A_tran; k.B_transpose = B_tran; k.flipxy = flipxy;
+    k.AxB_method = d ? d->axb : GBA_DEFAULT;
+    k.do_sort = d ? d->do_sort : 0;
+    return k;
+}
+
+extern "C" {
+
+gba_info gba_mxm(gba_matrix *C, const gba_matrix *M, const gba_binop *accum, const gba_semiring *semiring,
+                 const gba_matrix *A, const gba_matrix *B, const gba_descriptor *desc, gba_report *report) {
+    if (!semiring) { set_error("semiring is NULL"); return GBA_NULL_POINTER; }
+    Call k = make_call(C, M, accum, semiring, A, desc && desc->in0 == GBA_TRAN, B, desc && desc->in1 == GBA_TRAN, false, desc);
+    return mxm_driver(k, report, false);
+}
+
+gba_info gba_mxm_select(const gba_matrix *C, const gba_matrix *M, const gba_binop *accum, const gba_semiring *semiring,
+                        const gba_matrix *A, const gba_matrix *B, const gba_descriptor *desc, gba_report *report) {
+    if (!semiring) { set_error("semiring is NULL"); return GBA_NULL_POINTER; }
+    Call k = make_call(const_cast<gba_matrix *>(C), M, accum, semiring, A, desc && desc->in0 == GBA_TRAN, B,
+                       desc && desc->in1 == GBA_TRAN, false, desc);
+    return mxm_driver(k, report, true);
+}
+
+// w<M> = accum (w, A*u): u and w are n-by-1 CSC matrices (Source/GrB_mxv.c:57-66)
+gba_info gba_mxv(gba_matrix *w, const gba_matrix *mask, const gba_binop *accum, const gba_semiring *semiring,
+                 const gba_matrix *A, const gba_matrix *u, const gba_descriptor *desc, gba_report *report) {
+    if (!semiring) { set_error("semiring is NULL"); return GBA_NULL_POINTER; }
+    Call k = make_call(w, mask, accum, semiring, A, desc && desc->in0 == GBA_TRAN, u, false, false, desc);
+    return mxm_driver(k, report, false);
+}
+
+// w'<M'> = accum (w', u'*A): operands swapped, A_transpose negated, flipxy true (Source/GrB_vxm.c:63-72)
+gba_info gba_vxm(gba_matrix *w, const gba_matrix *mask, const gba_binop *accum, const gba_semiring *semiring,
+                 const gba_matrix *u, const gba_matrix *A, const gba_descriptor *desc, gba_report *report) {
+    if (!semiring) { set_error("semiring is NULL"); return GBA_NULL_POINTER; }
+    const bool A_tran = desc && desc->in1 == GBA_TRAN;
+    Call k = make_call(w, mask, accum, semiring, A, !A_tran, u, false, true, desc);
+    return mxm_driver(k, report, false);
+}
+
+// ---- per-method entry points: operands are CSC-agnostic vector matrices ----
+static gba_info canon_for(const gba_semiring *s, const gba_matrix *A, const gba_matrix *B, Canon *c) {
+    if (!s || !A || !B) { set_error("NULL argument"); return GBA_NULL_POINTER; }
+    return canonicalize(s, false, A->type, B->type, c);
+}
+
+gba_info gba_AxB_saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
+                        const gba_matrix *A, const gba_matrix *B, const gba_semiring *semiring,
+                        int32_t axb_method, int32_t do_sort, bool *mask_applied, gba_report *report) {
+    Canon c; GBA_OK(canon_for(semiring, A, B, &c));
+    if (report) { *report = gba_report{}; report->method = GBA_METHOD_SAXPY3; report->flops = -1; }
+    return saxpy3(C, M, Mask_comp, Mask_struct, A, B, c, axb_method, do_sort, mask_applied, report);
+}
+
+gba_info gba_AxB_saxpy3_flopcount(int64_t *Mwork, int64_t *Bflops_dev, const gba_matrix *M, bool Mask_comp,
+                                  const gba_matrix *A, const gba_matrix *B) {
+    if (!Bflops_dev || !A || !B) { set_error("NULL argument"); return GBA_NULL_POINTER; }
+    GBA_OK(saxpy3_flopcount(Mwork, Bflops_dev, M, Mask_comp, A, B));
+    return dev_cumsum_i64(Bflops_dev, B->nvec, ctx().stream);
+}
+
+gba_info gba_AxB_dot3(gba_matrix *C, const gba_matrix *M, bool Mask_struct, const gba_matrix *A, const gba_matrix *B,
+                      const gba_semiring *semiring, gba_report *report) {
+    Canon c; GBA_OK(canon_for(semiring, A, B, &c));
+    if (report) { *report = gba_report{}; report->method = GBA_METHOD_DOT3; report->flops = -1; }
+    return dot3(C, M, Mask_struct, A, B, c, report);
+}
+
+gba_info gba_AxB_dot2(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct, const gba_matrix *A,
+                      const gba_matrix *B, const gba_semiring *semiring, gba_report *report) {
+    Canon c; GBA_OK(canon_for(semiring, A, B, &c));
+    if (report) { *report = gba_report{}; report->method = GBA_METHOD_DOT2; report->flops = -1; }
+    return dot2(C, M, Mask_comp, Mask_struct, A, B, c, report);
+}
+
+gba_info gba_AxB_dot4(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const gba_semiring *semiring,
+                      gba_report *report) {
+    Canon c; GBA_OK(canon_for(semiring, A, B, &c));
+    if (report) { *report = gba_report{}; report->method = GBA_METHOD_DOT4; report->flops = -1; }
+    return dot4(C, A, B, c, report);
+}
+
+gba_info gba_AxB_saxpy4(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const gba_semiring *semiring,
+                        gba_report *report) {
+    Canon c; GBA_OK(canon_for(semiring, A, B, &c));
+    if (report) { *report = gba_report{}; report->method = GBA_METHOD_SAXPY4; report->flops = -1; }
+    return saxpy4(C, A, B, c, report);
+}
+
+gba_info gba_AxB_saxpy5(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const gba_semiring *semiring,
+                        gba_report *report) {
+    Canon c; GBA_OK(canon_for(semiring, A, B, &c));
+    if (report) { *report = gba_report{}; report->method = GBA_METHOD_SAXPY5; report->flops = -1; }
+    return saxpy5(C, A, B, c, report);
+}
+
+gba_info gba_AxB_saxbit(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct, const gba_matrix *A,
+                        const gba_matrix *B, const gba_semiring *semiring, gba_report *report) {
+    Canon c; GBA_OK(canon_for(semiring, A, B, &c));
+    if (report) { *report = gba_report{}; report->method = GBA_METHOD_SAXBIT; report->flops = -1; }
+    return saxbit(C, M, Mask_comp, Mask_struct, A, B, c, report);
+}
+
+gba_info gba_matrix_wait(gba_matrix *C) {
+    if (!C) { set_error("C is NULL"); return GBA_NULL_POINTER; }
+    return matrix_wait(C);
+}
+
+gba_info gba_transpose(gba_matrix *AT, const gba_matrix *A) {
+    if (!AT || !A) { set_error("NULL argument"); return GBA_NULL_POINTER; }
+    return transpose(AT, A);
+}
+
+}  // extern "C"

@@ -1,0 +1,454 @@
+// Library context, device memory, prefix sums and the semiring canonicaliser.
+#include "gba_internal.hpp"
+#include <mutex>
+#include <cstring>
+
+namespace gba {
+
+// ------------------------------------------------------------------ errors --
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static Context g_ctx;
+Context &ctx() { return g_ctx; }
+
+gba_info require_init() {
+    if (!g_ctx.inited) GBA_FAIL(GBA_UNINITIALIZED_OBJECT, "gba_init has not been called");
+    return GBA_SUCCESS;
+}
+
+// ------------------------------------------------------------- prefix sum --
+// Three-step exclusive scan over n+1 slots (slot n holds the total):
+// per-tile sums, scan of the tile sums (recursively), per-tile scan + offset.
+static constexpr int SCAN_THREADS = 256;
+static constexpr int SCAN_ITEMS = 8;
+static constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ inline int64_t wave_incl_scan(int64_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int64_t u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_tile_sums(const int64_t *__restrict__ a, int64_t n, int64_t *__restrict__ tile_sum) {
+    __shared__ int64_t wsum[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    int64_t s = 0;
+#pragma unroll
+    for (int it = 0; it < SCAN_ITEMS; it++) {
+        int64_t idx = base + it * SCAN_THREADS + threadIdx.x;
+        if (idx < n) s += a[idx];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; w++) t += wsum[w];
+        tile_sum[blockIdx.x] = t;
+    }
+}
+
+// each thread owns SCAN_ITEMS consecutive slots of its tile
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_tiles(int64_t *__restrict__ a, int64_t n, const int64_t *__restrict__ tile_off) {
+    __shared__ int64_t wsum[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t v[SCAN_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int it = 0; it < SCAN_ITEMS; it++) {
+        int64_t idx = base + it;
+        v[it] = (idx < n) ? a[idx] : 0;
+        s += v[it];
+    }
+    int64_t incl = wave_incl_scan(s);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[w] = incl;
+    __syncthreads();
+    int64_t off = tile_off[blockIdx.x];
+    for (int q = 0; q < w; q++) off += wsum[q];
+    int64_t run = off + incl - s;
+#pragma unroll
+    for (int it = 0; it < SCAN_ITEMS; it++) {
+        int64_t idx = base + it;
+        if (idx <= n) a[idx] = run;
+        run += v[it];
+    }
+}
+
+gba_info dev_cumsum_i64(int64_t *count, int64_t n, hipStream_t st) {
+    if (n < 0) GBA_FAIL(GBA_INVALID_VALUE, "cumsum: n < 0");
+    const int64_t slots = n + 1;
+    const int64_t ntiles = ceil_div(slots, SCAN_TILE);
+    DevBuf sums;
+    GBA_OK(sums.alloc((size_t)(ntiles + 1) * sizeof(int64_t)));
+    hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, st, count, n, sums.as<int64_t>());
+    if (ntiles > 1) {
+        GBA_OK(dev_cumsum_i64(sums.as<int64_t>(), ntiles, st));
+    } else {
+        GBA_HIP(hipMemsetAsync(sums.p, 0, sizeof(int64_t), st));
+    }
+    hipLaunchKernelGGL(scan_tiles, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, st, count, n, sums.as<int64_t>());
+    GBA_HIP(hipGetLastError());
+    GBA_HIP(hipStreamSynchronize(st));   // sums is freed on return
+    return GBA_SUCCESS;
+}
+
+__global__ void fill_i64_kernel(int64_t *p, int64_t n, int64_t v) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx < n; idx += stride) p[idx] = v;
+}
+gba_info dev_fill_i64(int64_t *p, int64_t n, int64_t v, hipStream_t st) {
+    if (n <= 0) return GBA_SUCCESS;
+    int64_t blocks = ceil_div(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n, v);
+    GBA_HIP(hipGetLastError());
+    return GBA_SUCCESS;
+}
+gba_info dev_fill_bytes(void *p, size_t n, int byte, hipStream_t st) {
+    if (n == 0) return GBA_SUCCESS;
+    GBA_HIP(hipMemsetAsync(p, byte, n, st));
+    return GBA_SUCCESS;
+}
+
+__global__ void max_diff_kernel(const int64_t *__restrict__ p, int64_t n, unsigned long long *out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t m = 0;
+    for (; idx < n; idx += stride) { int64_t d = p[idx + 1] - p[idx]; m = d > m ? d : m; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { int64_t o = __shfl_down(m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, (unsigned long long)m);
+}
+gba_info dev_max_diff_i64(const int64_t *p, int64_t n, int64_t *out_host) {
+    *out_host = 0;
+    if (n <= 0) return GBA_SUCCESS;
+    DevBuf o; GBA_OK(o.alloc(8));
+    hipStream_t st = ctx().stream;
+    GBA_HIP(hipMemsetAsync(o.p, 0, 8, st));
+    int64_t blocks = ceil_div(n, 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(max_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n, o.as<unsigned long long>());
+    GBA_HIP(hipMemcpyAsync(out_host, o.p, 8, hipMemcpyDeviceToHost, st));
+    GBA_HIP(hipStreamSynchronize(st));
+    return GBA_SUCCESS;
+}
+gba_info dev_read_i64(const int64_t *p, int64_t *out_host) {
+    hipStream_t st = ctx().stream;
+    GBA_HIP(hipMemcpyAsync(out_host, p, 8, hipMemcpyDeviceToHost, st));
+    GBA_HIP(hipStreamSynchronize(st));
+    return GBA_SUCCESS;
+}
+
+__global__ void count_nonempty_kernel(const int64_t *__restrict__ p, int64_t n, unsigned long long *out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (; idx < n; idx += stride) c += (p[idx + 1] > p[idx]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+// GB_nvec_nonempty (Source/GB_nvec_nonempty.c)
+gba_info dev_count_nonempty(const int64_t *p, int64_t nvec, int64_t *out_host) {
+    *out_host = 0;
+    if (nvec <= 0) return GBA_SUCCESS;
+    DevBuf o; GBA_OK(o.alloc(8));
+    hipStream_t st = ctx().stream;
+    GBA_HIP(hipMemsetAsync(o.p, 0, 8, st));
+    int64_t blocks = ceil_div(nvec, 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(count_nonempty_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, nvec, o.as<unsigned long long>());
+    GBA_HIP(hipMemcpyAsync(out_host, o.p, 8, hipMemcpyDeviceToHost, st));
+    GBA_HIP(hipStreamSynchronize(st));
+    return GBA_SUCCESS;
+}
+
+// GB_is_diagonal (Source/GB_is_diagonal.c): square, nvals == n, every vector j holds exactly entry j
+__global__ void is_diag_kernel(const int64_t *__restrict__ p, const int64_t *__restrict__ i, int64_t n, int *bad) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    int64_t s = p[j];
+    if (p[j + 1] - s != 1 || i[s] != j) *bad = 1;
+}
+gba_info dev_is_diagonal(const gba_matrix *A, bool *out) {
+    *out = false;
+    if (!is_sparse(A) || A->vlen != A->vdim || A->nvals != A->vdim || A->nzombies != 0) return GBA_SUCCESS;
+    const int64_t n = A->vdim;
+    if (n == 0) { return GBA_SUCCESS; }
+    DevBuf o; GBA_OK(o.alloc(4));
+    hipStream_t st = ctx().stream;
+    GBA_HIP(hipMemsetAsync(o.p, 0, 4, st));
+    hipLaunchKernelGGL(is_diag_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, A->p, A->i, n, o.as<int>());
+    int bad = 0;
+    GBA_HIP(hipMemcpyAsync(&bad, o.p, 4, hipMemcpyDeviceToHost, st));
+    GBA_HIP(hipStreamSynchronize(st));
+    *out = (bad == 0);
+    return GBA_SUCCESS;
+}
+
+// ------------------------------------------------------ semiring canonical --
+// GB_flip_binop (Source/GB_flip_binop.c:355-375)
+int flip_binop(int op, bool *flipxy) {
+    if (!*flipxy) return op;
+    *flipxy = false;
+    switch (op) {
+        case GBA_FIRST: return GBA_SECOND;   case GBA_SECOND: return GBA_FIRST;
+        case GBA_MINUS: return GBA_RMINUS;   case GBA_RMINUS: return GBA_MINUS;
+        case GBA_DIV: return GBA_RDIV;       case GBA_RDIV: return GBA_DIV;
+        case GBA_GT: return GBA_LT;          case GBA_LT: return GBA_GT;
+        case GBA_GE: return GBA_LE;          case GBA_LE: return GBA_GE;
+        case GBA_ISGT: return GBA_ISLT;      case GBA_ISLT: return GBA_ISGT;
+        case GBA_ISGE: return GBA_ISLE;      case GBA_ISLE: return GBA_ISGE;
+        case GBA_FIRSTI: return GBA_SECONDJ;   case GBA_SECONDJ: return GBA_FIRSTI;
+        case GBA_FIRSTI1: return GBA_SECONDJ1; case GBA_SECONDJ1: return GBA_FIRSTI1;
+        case GBA_FIRSTJ: return GBA_SECONDI;   case GBA_SECONDI: return GBA_FIRSTJ;
+        case GBA_FIRSTJ1: return GBA_SECONDI1; case GBA_SECONDI1: return GBA_FIRSTJ1;
+        // commutative: unchanged
+        case GBA_ANY: case GBA_PAIR: case GBA_MIN: case GBA_MAX: case GBA_PLUS: case GBA_TIMES:
+        case GBA_ISEQ: case GBA_ISNE: case GBA_EQ: case GBA_NE:
+        case GBA_LOR: case GBA_LAND: case GBA_LXOR:
+        case GBA_BOR: case GBA_BAND: case GBA_BXOR: case GBA_BXNOR:
+            return op;
+        default:
+            *flipxy = true;   // cannot be flipped: not a built-in semiring any more
+            return op;
+    }
+}
+
+// GB_boolean_rename (Source/GB_boolean_rename.c:45-97)
+int boolean_rename(int op) {
+    switch (op) {
+        case GBA_DIV: return GBA_FIRST;
+        case GBA_RDIV: return GBA_SECOND;
+        case GBA_MIN: case GBA_TIMES: return GBA_LAND;
+        case GBA_MAX: case GBA_PLUS: return GBA_LOR;
+        case GBA_MINUS: case GBA_RMINUS: case GBA_NE: case GBA_ISNE: return GBA_LXOR;
+        case GBA_ISEQ: return GBA_EQ;
+        case GBA_ISGT: return GBA_GT;
+        case GBA_ISLT: return GBA_LT;
+        case GBA_POW: case GBA_ISGE: return GBA_GE;
+        case GBA_ISLE: return GBA_LE;
+        default: return op;
+    }
+}
+
+static bool is_real_type(int t) { return t >= GBA_BOOL && t <= GBA_FP64; }
+static bool is_uint_type(int t) { return t == GBA_UINT8 || t == GBA_UINT16 || t == GBA_UINT32 || t == GBA_UINT64; }
+
+// GB_AxB_semiring_builtin (Source/GB_AxB_semiring_builtin.c:20-123) +
+// GB_binop_builtin (Source/GB_binop_builtin.c:68-88)
+gba_info canonicalize(const gba_semiring *s, bool flipxy, int atype, int btype, Canon *out) {
+    if (!s) GBA_FAIL(GBA_NULL_POINTER, "semiring is NULL");
+    int mult = s->mult, add = s->add;
+    if (mult == GBA_USER_BINOP || add == GBA_USER_BINOP || mult < GBA_FIRST || mult > GBA_SECONDJ1)
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "user-defined or unknown operator in semiring (add %d mult %d)", add, mult);
+    mult = flip_binop(mult, &flipxy);
+    if (flipxy) GBA_FAIL(GBA_NOT_IMPLEMENTED, "multiplier %d cannot be flipped", mult);
+    Canon c;
+    if (op_is_positional(mult)) {
+        if (mult == GBA_SECONDI) mult = GBA_FIRSTJ;
+        if (mult == GBA_SECONDI1) mult = GBA_FIRSTJ1;
+        if (s->ztype != GBA_INT32 && s->ztype != GBA_INT64)
+            GBA_FAIL(GBA_DOMAIN_MISMATCH, "positional multiplier needs an int32/int64 monoid");
+        if (!(add == GBA_MIN || add == GBA_MAX || add == GBA_TIMES || add == GBA_PLUS || add == GBA_ANY))
+            GBA_FAIL(GBA_NOT_IMPLEMENTED, "monoid %d with a positional multiplier", add);
+        c.kind = KIND_POS; c.add = add; c.mult = mult; c.xtype = GBA_UINT8; c.ztype = s->ztype;
+        c.a_pattern = c.b_pattern = true;
+        *out = c;
+        return GBA_SUCCESS;
+    }
+    int xtype = s->xtype, ztype = s->ztype;
+    if (!is_real_type(ztype)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "ztype %d (complex/user types stay on the CPU)", ztype);
+    const bool a_pat = (mult == GBA_SECOND || mult == GBA_PAIR);
+    const bool b_pat = (mult == GBA_FIRST || mult == GBA_PAIR);
+    if (mult == GBA_PAIR) xtype = ztype;
+    if (!is_real_type(xtype)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "xtype %d", xtype);
+    if (!a_pat && !b_pat && s->ytype != s->xtype) GBA_FAIL(GBA_NOT_IMPLEMENTED, "multiplier with different x and y types");
+    if (a_pat && !b_pat) xtype = s->ytype;
+    // boolean renames
+    if (xtype == GBA_BOOL) mult = boolean_rename(mult);
+    if (ztype == GBA_BOOL) {
+        if (add == GBA_MIN || add == GBA_TIMES) add = GBA_LAND;
+        else if (add == GBA_MAX || add == GBA_PLUS) add = GBA_LOR;
+    }
+    const bool mult_is_cmp = (mult >= GBA_EQ && mult <= GBA_LE);
+    if (mult_is_cmp && xtype != GBA_BOOL) {
+        if (ztype != GBA_BOOL) GBA_FAIL(GBA_DOMAIN_MISMATCH, "comparator multiplier needs a boolean monoid");
+        c.kind = KIND_CMP;
+    } else {
+        if (xtype != ztype) GBA_FAIL(GBA_NOT_IMPLEMENTED, "multiplier output type differs from monoid type (typecast)");
+        c.kind = KIND_TT;
+    }
+    // monoid must be a built-in one for its type
+    if (ztype == GBA_BOOL) {
+        if (!(add == GBA_LOR || add == GBA_LAND || add == GBA_LXOR || add == GBA_EQ || add == GBA_ANY))
+            GBA_FAIL(GBA_NOT_IMPLEMENTED, "boolean monoid %d", add);
+    } else if (add == GBA_BOR || add == GBA_BAND || add == GBA_BXOR || add == GBA_BXNOR) {
+        if (!is_uint_type(ztype)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "bitwise monoid on type %d", ztype);
+    } else if (!(add == GBA_MIN || add == GBA_MAX || add == GBA_PLUS || add == GBA_TIMES || add == GBA_ANY)) {
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "monoid %d on type %d", add, ztype);
+    }
+    if ((mult == GBA_BOR || mult == GBA_BAND || mult == GBA_BXOR || mult == GBA_BXNOR) && !is_uint_type(xtype))
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "bitwise multiplier on type %d", xtype);
+    if (mult == GBA_ANY || mult == GBA_POW) GBA_FAIL(GBA_NOT_IMPLEMENTED, "multiplier %d", mult);
+    // ANY_PAIR collapse (Source/GB_AxB_semiring_builtin.c:108-120): the result is 1 everywhere
+    if (mult == GBA_PAIR && (add == GBA_EQ || add == GBA_LAND || add == GBA_BAND || add == GBA_LOR ||
+                             add == GBA_BOR || add == GBA_MAX || add == GBA_MIN || add == GBA_TIMES))
+        add = GBA_ANY;
+    // no typecasting of the operands on the device (Source/GB_binop_builtin.c:68-88)
+    if (!a_pat && atype != xtype) GBA_FAIL(GBA_NOT_IMPLEMENTED, "A has type %d but the multiplier wants %d (typecast)", atype, xtype);
+    if (!b_pat && btype != xtype) GBA_FAIL(GBA_NOT_IMPLEMENTED, "B has type %d but the multiplier wants %d (typecast)", btype, xtype);
+    c.add = add; c.mult = mult; c.xtype = xtype; c.ztype = ztype; c.a_pattern = a_pat; c.b_pattern = b_pat;
+    *out = c;
+    return GBA_SUCCESS;
+}
+
+gba_info stage_to_device(const gba_matrix *in, gba_matrix *out, std::vector<void *> &owned) {
+    *out = *in;
+    if (in->mem == GBA_MEM_DEVICE) return GBA_SUCCESS;
+    hipStream_t st = ctx().stream;
+    auto up = [&](const void *src, size_t bytes, void **dst) -> gba_info {
+        *dst = nullptr;
+        if (!src) return GBA_SUCCESS;
+        void *d = gba_malloc(bytes ? bytes : 1);
+        if (!d) GBA_FAIL(GBA_OUT_OF_MEMORY, "staging %zu bytes", bytes);
+        owned.push_back(d);
+        GBA_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, st));
+        *dst = d;
+        return GBA_SUCCESS;
+    };
+    const size_t xs = type_size(in->type);
+    const int64_t held = nnz_held(in);
+    const int64_t dense = in->vlen * in->vdim;
+    GBA_OK(up(in->p, (size_t)(in->nvec + 1) * 8, (void **)&out->p));
+    GBA_OK(up(in->h, (size_t)in->nvec * 8, (void **)&out->h));
+    GBA_OK(up(in->i, (size_t)in->nvals * 8, (void **)&out->i));
+    GBA_OK(up(in->b, (size_t)dense, (void **)&out->b));
+    const int64_t nx = in->iso ? 1 : (is_dense_fmt(in) ? dense : held);
+    GBA_OK(up(in->x, (size_t)nx * xs, &out->x));
+    GBA_HIP(hipStreamSynchronize(st));
+    out->mem = GBA_MEM_DEVICE;
+    return GBA_SUCCESS;
+}
+
+}  // namespace gba
+
+// ============================================================== C ABI ======
+using namespace gba;
+
+extern "C" {
+
+gba_info gba_init(int device) {
+    Context &c = ctx();
+    if (c.inited && c.device == device) return GBA_SUCCESS;
+    if (c.inited) gba_finalize();
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        GBA_FAIL(GBA_PANIC, "no HIP device is visible (%s): libgraphblas_amd has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= count) GBA_FAIL(GBA_INVALID_VALUE, "device %d out of range (0..%d)", device, count - 1);
+    GBA_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    GBA_HIP(hipGetDeviceProperties(&prop, device));
+    c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    GBA_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    GBA_HIP(hipEventCreate(&c.ev0));
+    GBA_HIP(hipEventCreate(&c.ev1));
+    c.device = device;
+    c.inited = true;
+    return GBA_SUCCESS;
+}
+
+gba_info gba_finalize(void) {
+    Context &c = ctx();
+    if (!c.inited) return GBA_SUCCESS;
+    hipStreamSynchronize(c.stream);
+    hipEventDestroy(c.ev0);
+    hipEventDestroy(c.ev1);
+    hipStreamDestroy(c.stream);
+    c = Context();
+    return GBA_SUCCESS;
+}
+
+const char *gba_last_error(void) { return g_err; }
+const char *gba_version(void) { return "graphblas_amd 0.1 (gfx950); mirrors SuiteSparse:GraphBLAS 9.1.0 mxm/mxv/vxm"; }
+
+void *gba_malloc(size_t nbytes) {
+    if (!ctx().inited) { set_error("gba_malloc before gba_init"); return nullptr; }
+    void *p = nullptr;
+    if (hipMalloc(&p, nbytes ? nbytes : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void gba_free(void *p) { if (p) (void)hipFree(p); }
+
+gba_info gba_memcpy_h2d(void *dst, const void *src, size_t nbytes) {
+    GBA_OK(require_init());
+    if (nbytes == 0) return GBA_SUCCESS;
+    GBA_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, ctx().stream));
+    GBA_HIP(hipStreamSynchronize(ctx().stream));
+    return GBA_SUCCESS;
+}
+gba_info gba_memcpy_d2h(void *dst, const void *src, size_t nbytes) {
+    GBA_OK(require_init());
+    if (nbytes == 0) return GBA_SUCCESS;
+    GBA_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx().stream));
+    GBA_HIP(hipStreamSynchronize(ctx().stream));
+    return GBA_SUCCESS;
+}
+gba_info gba_memset(void *dst, int byte, size_t nbytes) {
+    GBA_OK(require_init());
+    if (nbytes == 0) return GBA_SUCCESS;
+    GBA_HIP(hipMemsetAsync(dst, byte, nbytes, ctx().stream));
+    return GBA_SUCCESS;
+}
+gba_info gba_sync(void) {
+    GBA_OK(require_init());
+    GBA_HIP(hipStreamSynchronize(ctx().stream));
+    return GBA_SUCCESS;
+}
+void *gba_stream(void) { return (void *)ctx().stream; }
+
+gba_info gba_timer_start(void) {
+    GBA_OK(require_init());
+    GBA_HIP(hipEventRecord(ctx().ev0, ctx().stream));
+    return GBA_SUCCESS;
+}
+gba_info gba_timer_stop(double *ms) {
+    GBA_OK(require_init());
+    GBA_HIP(hipEventRecord(ctx().ev1, ctx().stream));
+    GBA_HIP(hipEventSynchronize(ctx().ev1));
+    float f = 0.f;
+    GBA_HIP(hipEventElapsedTime(&f, ctx().ev0, ctx().ev1));
+    if (ms) *ms = (double)f;
+    return GBA_SUCCESS;
+}
+
+void gba_matrix_free_content(gba_matrix *A) {
+    if (!A) return;
+    if (A->mem == GBA_MEM_DEVICE) {
+        gba_free(A->p); gba_free(A->h); gba_free(A->i); gba_free(A->x); gba_free(A->b);
+    }
+    A->p = A->h = A->i = nullptr; A->x = nullptr; A->b = nullptr;
+    A->nvals = 0; A->nzombies = 0;
+}
+
+gba_info gba_cumsum(int64_t *count_dev, int64_t n) {
+    GBA_OK(require_init());
+    if (!count_dev) GBA_FAIL(GBA_NULL_POINTER, "count is NULL");
+    return dev_cumsum_i64(count_dev, n, ctx().stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,317 @@
+// Finishing passes around the multiply kernels:
+//   matrix_wait   kill zombies + sort every vector   (Source/GB_wait.c, Source/GB_unjumble.c)
+//   transpose     AT = A', bucket method             (Source/GB_transpose_bucket.c, GB_transpose_cast.c:1-38)
+//   partition     flop-balanced 1-D split            (Source/GB_pslice.c:116)
+#include "gba_internal.hpp"
+#include <algorithm>
+
+namespace gba {
+
+// --------------------------------------------------------------- count ones --
+__global__ void __launch_bounds__(256)
+count_ones_kernel(const int8_t *__restrict__ b, int64_t n, unsigned long long *__restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (; idx < n; idx += stride) c += (b[idx] != 0);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+gba_info dev_count_ones(const int8_t *b, int64_t n, int64_t *out) {
+    *out = 0;
+    if (n <= 0) return GBA_SUCCESS;
+    hipStream_t st = ctx().stream;
+    DevBuf o; GBA_OK(o.alloc(8));
+    GBA_HIP(hipMemsetAsync(o.p, 0, 8, st));
+    int64_t blocks = ceil_div(n, 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(count_ones_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b, n, o.as<unsigned long long>());
+    GBA_HIP(hipMemcpyAsync(out, o.p, 8, hipMemcpyDeviceToHost, st));
+    GBA_HIP(hipStreamSynchronize(st));
+    return GBA_SUCCESS;
+}
+
+// ------------------------------------------------------------ kill zombies --
+__global__ void __launch_bounds__(256)
+count_live_kernel(int64_t nvec, const int64_t *__restrict__ Cp, const int64_t *__restrict__ Ci, int64_t *__restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; j < nvec; j += stride) {
+        const int64_t p1 = Cp[j + 1];
+        int c = 0;
+        for (int64_t p = Cp[j] + lane; p < p1; p += 64) c += (Ci[p] >= 0);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+        if (lane == 0) cnt[j] = c;
+    }
+}
+
+// order-preserving compaction, one wavefront per vector
+__global__ void __launch_bounds__(256)
+compact_live_kernel(int64_t nvec, const int64_t *__restrict__ Cp, const int64_t *__restrict__ Ci,
+                    const uint8_t *__restrict__ Cx, int esize, const int64_t *__restrict__ Np,
+                    int64_t *__restrict__ Ni, uint8_t *__restrict__ Nx) {
+    const int lane = threadIdx.x & 63;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; j < nvec; j += stride) {
+        const int64_t p0 = Cp[j], p1 = Cp[j + 1];
+        int64_t out = Np[j];
+        for (int64_t base = p0; base < p1; base += 64) {
+            const int64_t p = base + lane;
+            const bool live = (p < p1) && (Ci[p] >= 0);
+            const unsigned long long m = __ballot(live);
+            if (live) {
+                const int64_t q = out + __builtin_popcountll(m & ((1ull << lane) - 1));
+                Ni[q] = Ci[p];
+                for (int b = 0; b < esize; b++) Nx[q * esize + b] = Cx[p * esize + b];
+            }
+            out += __builtin_popcountll(m);
+        }
+    }
+}
+
+// ------------------------------------------------------------- vector sort --
+// bitonic sort of one vector in LDS: (index, original position) pairs, then the
+// values are permuted through LDS as well.  n <= SORT_MAX.
+static constexpr int SORT_MAX = 4096;
+static constexpr int SORT_THREADS = 256;
+
+__global__ void __launch_bounds__(SORT_THREADS)
+sort_vectors_lds_kernel(int64_t nlist, const int64_t *__restrict__ list, const int64_t *__restrict__ Cp,
+                        int64_t *__restrict__ Ci, uint8_t *__restrict__ Cx, int esize) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int64_t *key = reinterpret_cast<int64_t *>(smem);                        // SORT_MAX
+    int32_t *pos = reinterpret_cast<int32_t *>(smem + (size_t)SORT_MAX * 8);  // SORT_MAX
+    uint8_t *val = smem + (size_t)SORT_MAX * 12;                              // SORT_MAX * 8
+    for (int64_t li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int64_t j = list[li];
+        const int64_t p0 = Cp[j];
+        const int n = (int)(Cp[j + 1] - p0);
+        int np2 = 1; while (np2 < n) np2 <<= 1;
+        for (int t = threadIdx.x; t < np2; t += SORT_THREADS) {
+            key[t] = (t < n) ? Ci[p0 + t] : INT64_MAX;
+            pos[t] = t;
+        }
+        for (int t = threadIdx.x; t < n * esize; t += SORT_THREADS) val[t] = Cx[p0 * esize + t];
+        __syncthreads();
+        for (int ksz = 2; ksz <= np2; ksz <<= 1) {
+            for (int jsz = ksz >> 1; jsz > 0; jsz >>= 1) {
+                for (int t = threadIdx.x; t < np2; t += SORT_THREADS) {
+                    const int u = t ^ jsz;
+                    if (u > t) {
+                        const bool up = ((t & ksz) == 0);
+                        const int64_t a = key[t], b = key[u];
+                        if ((a > b) == up) { key[t] = b; key[u] = a; const int32_t q = pos[t]; pos[t] = pos[u]; pos[u] = q; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int t = threadIdx.x; t < n; t += SORT_THREADS) {
+            Ci[p0 + t] = key[t];
+            const int src = pos[t];
+            for (int b = 0; b < esize; b++) Cx[(p0 + t) * esize + b] = val[src * esize + b];
+        }
+        __syncthreads();
+    }
+}
+
+// classify vectors: 0 already sorted / short, 1 LDS sort, 2 too long for LDS
+__global__ void __launch_bounds__(256)
+classify_sort_kernel(int64_t nvec, const int64_t *__restrict__ Cp, const int64_t *__restrict__ Ci,
+                     unsigned int *__restrict__ counters, int64_t *__restrict__ lds_list, int64_t *__restrict__ big_list) {
+    const int lane = threadIdx.x & 63;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; j < nvec; j += stride) {
+        const int64_t p0 = Cp[j], p1 = Cp[j + 1];
+        int bad = 0;
+        for (int64_t p = p0 + 1 + lane; p < p1; p += 64) bad |= (Ci[p - 1] > Ci[p]);
+        bad = __any(bad);
+        if (bad && lane == 0) {
+            if (p1 - p0 <= SORT_MAX) { unsigned int q = atomicAdd(&counters[0], 1u); lds_list[q] = j; }
+            else { unsigned int q = atomicAdd(&counters[1], 1u); big_list[q] = j; }
+        }
+    }
+}
+
+gba_info matrix_wait(gba_matrix *C) {
+    GBA_OK(require_init());
+    if (!is_sparse(C)) { C->jumbled = false; return GBA_SUCCESS; }      // bitmap/full: nothing pending
+    if (C->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_NOT_IMPLEMENTED, "wait on a host view");
+    hipStream_t st = ctx().stream;
+    const int64_t nvec = C->nvec;
+    const int esize = (int)type_size(C->type);
+    if (C->iso) GBA_FAIL(GBA_NOT_IMPLEMENTED, "wait on an iso matrix");
+    int64_t wblocks = ceil_div(nvec * 64, 256); if (wblocks > 8192) wblocks = 8192; if (wblocks < 1) wblocks = 1;
+    if (C->nzombies > 0) {
+        DevBuf Np;
+        GBA_OK(Np.alloc((size_t)(nvec + 1) * 8));
+        GBA_HIP(hipMemsetAsync(Np.p, 0, (size_t)(nvec + 1) * 8, st));
+        hipLaunchKernelGGL(count_live_kernel, dim3((unsigned)wblocks), dim3(256), 0, st, nvec, C->p, C->i, Np.as<int64_t>());
+        GBA_OK(dev_cumsum_i64(Np.as<int64_t>(), nvec, st));
+        int64_t nnz = 0;
+        GBA_OK(dev_read_i64(Np.as<int64_t>() + nvec, &nnz));
+        DevBuf Ni, Nx;
+        GBA_OK(Ni.alloc((size_t)(nnz > 0 ? nnz : 1) * 8));
+        GBA_OK(Nx.alloc((size_t)(nnz > 0 ? nnz : 1) * esize));
+        hipLaunchKernelGGL(compact_live_kernel, dim3((unsigned)wblocks), dim3(256), 0, st, nvec, C->p, C->i,
+                           reinterpret_cast<const uint8_t *>(C->x), esize, Np.as<int64_t>(), Ni.as<int64_t>(), Nx.as<uint8_t>());
+        GBA_HIP(hipGetLastError());
+        GBA_HIP(hipStreamSynchronize(st));
+        gba_free(C->p); gba_free(C->i); gba_free(C->x);
+        C->p = reinterpret_cast<int64_t *>(Np.release());
+        C->i = reinterpret_cast<int64_t *>(Ni.release());
+        C->x = Nx.release();
+        C->nvals = nnz; C->nzombies = 0;
+    }
+    if (C->jumbled && C->nvals > 1) {
+        DevBuf counters, lds_list, big_list;
+        GBA_OK(counters.alloc(8));
+        GBA_OK(lds_list.alloc((size_t)(nvec > 0 ? nvec : 1) * 8));
+        GBA_OK(big_list.alloc((size_t)(nvec > 0 ? nvec : 1) * 8));
+        GBA_HIP(hipMemsetAsync(counters.p, 0, 8, st));
+        hipLaunchKernelGGL(classify_sort_kernel, dim3((unsigned)wblocks), dim3(256), 0, st, nvec, C->p, C->i,
+                           counters.as<unsigned int>(), lds_list.as<int64_t>(), big_list.as<int64_t>());
+        unsigned int h[2] = {0, 0};
+        GBA_HIP(hipMemcpyAsync(h, counters.p, 8, hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipStreamSynchronize(st));
+        if (h[0] > 0) {
+            const size_t lds = (size_t)SORT_MAX * (8 + 4 + 8);
+            GBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sort_vectors_lds_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            unsigned int grid = h[0] > 16384 ? 16384 : h[0];
+            hipLaunchKernelGGL(sort_vectors_lds_kernel, dim3(grid), dim3(SORT_THREADS), lds, st, (int64_t)h[0],
+                               lds_list.as<int64_t>(), C->p, C->i, reinterpret_cast<uint8_t *>(C->x), esize);
+            GBA_HIP(hipGetLastError());
+        }
+        if (h[1] > 0) {
+            // Vectors longer than the LDS sort: sorted on the host, one at a time.  The device kernels
+            // of this library never produce them (long vectors leave saxpy3 already ordered).
+            std::vector<int64_t> big(h[1]);
+            GBA_HIP(hipMemcpyAsync(big.data(), big_list.p, (size_t)h[1] * 8, hipMemcpyDeviceToHost, st));
+            GBA_HIP(hipStreamSynchronize(st));
+            for (int64_t j : big) {
+                int64_t pp[2];
+                GBA_HIP(hipMemcpy(pp, C->p + j, 16, hipMemcpyDeviceToHost));
+                const int64_t n = pp[1] - pp[0];
+                std::vector<int64_t> idx((size_t)n), ord((size_t)n);
+                std::vector<uint8_t> vals((size_t)n * esize), nv((size_t)n * esize);
+                GBA_HIP(hipMemcpy(idx.data(), C->i + pp[0], (size_t)n * 8, hipMemcpyDeviceToHost));
+                GBA_HIP(hipMemcpy(vals.data(), reinterpret_cast<uint8_t *>(C->x) + pp[0] * esize, (size_t)n * esize, hipMemcpyDeviceToHost));
+                for (int64_t t = 0; t < n; t++) ord[(size_t)t] = t;
+                std::sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) { return idx[(size_t)a] < idx[(size_t)b]; });
+                std::vector<int64_t> ni((size_t)n);
+                for (int64_t t = 0; t < n; t++) {
+                    ni[(size_t)t] = idx[(size_t)ord[(size_t)t]];
+                    for (int b = 0; b < esize; b++) nv[(size_t)t * esize + b] = vals[(size_t)ord[(size_t)t] * esize + b];
+                }
+                GBA_HIP(hipMemcpy(C->i + pp[0], ni.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+                GBA_HIP(hipMemcpy(reinterpret_cast<uint8_t *>(C->x) + pp[0] * esize, nv.data(), (size_t)n * esize, hipMemcpyHostToDevice));
+            }
+        }
+        GBA_HIP(hipStreamSynchronize(st));
+    }
+    C->jumbled = false;
+    return GBA_SUCCESS;
+}
+
+// --------------------------------------------------------------- transpose --
+__global__ void __launch_bounds__(256)
+transpose_count_kernel(int64_t anz, const int64_t *__restrict__ Ai, unsigned long long *__restrict__ cnt) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < anz; p += stride) atomicAdd(&cnt[Ai[p]], 1ull);
+}
+
+__global__ void __launch_bounds__(256)
+transpose_fill_kernel(int64_t nvec, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                      const uint8_t *__restrict__ Ax, bool A_iso, int esize, unsigned long long *__restrict__ cursor,
+                      int64_t *__restrict__ Ti, uint8_t *__restrict__ Tx) {
+    const int lane = threadIdx.x & 63;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; j < nvec; j += stride) {
+        const int64_t p1 = Ap[j + 1];
+        for (int64_t p = Ap[j] + lane; p < p1; p += 64) {
+            const int64_t q = (int64_t)atomicAdd(&cursor[Ai[p]], 1ull);
+            Ti[q] = j;
+            const int64_t src = A_iso ? 0 : p;
+            for (int b = 0; b < esize; b++) Tx[q * esize + b] = Ax[src * esize + b];
+        }
+    }
+}
+
+gba_info transpose(gba_matrix *AT, const gba_matrix *A) {
+    GBA_OK(require_init());
+    if (!is_sparse(A)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "transpose: sparse matrices only");
+    if (A->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "transpose: zombies");
+    if (A->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_NOT_IMPLEMENTED, "transpose of a host view");
+    hipStream_t st = ctx().stream;
+    const int64_t anz = A->nvals, tvec = A->vlen, avec = A->nvec;
+    const int esize = (int)type_size(A->type);
+    DevBuf Tp, Ti, Tx, cur;
+    GBA_OK(Tp.alloc((size_t)(tvec + 1) * 8));
+    GBA_OK(cur.alloc((size_t)(tvec + 1) * 8));
+    GBA_OK(Ti.alloc((size_t)(anz > 0 ? anz : 1) * 8));
+    GBA_OK(Tx.alloc((size_t)(anz > 0 ? anz : 1) * (esize > 0 ? esize : 1)));
+    GBA_HIP(hipMemsetAsync(Tp.p, 0, (size_t)(tvec + 1) * 8, st));
+    if (anz > 0) {
+        int64_t blocks = ceil_div(anz, 256); if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(transpose_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, anz, A->i, Tp.as<unsigned long long>());
+    }
+    GBA_OK(dev_cumsum_i64(Tp.as<int64_t>(), tvec, st));
+    GBA_HIP(hipMemcpyAsync(cur.p, Tp.p, (size_t)(tvec + 1) * 8, hipMemcpyDeviceToDevice, st));
+    if (anz > 0) {
+        int64_t blocks = ceil_div(avec * 64, 256); if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(transpose_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avec, A->p, A->i,
+                           reinterpret_cast<const uint8_t *>(A->x), A->iso, esize, cur.as<unsigned long long>(),
+                           Ti.as<int64_t>(), Tx.as<uint8_t>());
+    }
+    GBA_HIP(hipGetLastError());
+    GBA_HIP(hipStreamSynchronize(st));
+    gba_matrix T = *A;
+    T.vlen = A->vdim; T.vdim = A->vlen; T.nvec = tvec; T.nvals = anz;
+    T.p = reinterpret_cast<int64_t *>(Tp.release());
+    T.i = reinterpret_cast<int64_t *>(Ti.release());
+    T.x = Tx.release();
+    T.h = nullptr; T.b = nullptr; T.iso = false; T.nzombies = 0; T.mem = GBA_MEM_DEVICE;
+    T.jumbled = true;
+    T.is_csc = A->is_csc;
+    gba_info info = matrix_wait(&T);        // bucket order -> sorted vectors
+    if (info != GBA_SUCCESS) { gba_matrix_free_content(&T); return info; }
+    *AT = T;
+    return GBA_SUCCESS;
+}
+
+}  // namespace gba
+
+using namespace gba;
+
+extern "C" gba_info gba_partition_by_flops(int64_t *part, int32_t nparts, const gba_matrix *A, const gba_matrix *B) {
+    GBA_OK(require_init());
+    if (!part || !A || !B) { set_error("NULL argument"); return GBA_NULL_POINTER; }
+    if (nparts < 1) { set_error("nparts < 1"); return GBA_INVALID_VALUE; }
+    // vectors of the "B" operand are the output vectors (for row-major matrices: the rows of the
+    // user's left operand).  Same flop count as saxpy3, then an even split of the prefix sum.
+    const int64_t nvec = B->nvec;
+    DevBuf fl; GBA_OK(fl.alloc((size_t)(nvec + 1) * 8));
+    GBA_OK(saxpy3_flopcount(nullptr, fl.as<int64_t>(), nullptr, false, A, B));
+    GBA_OK(dev_cumsum_i64(fl.as<int64_t>(), nvec, ctx().stream));
+    std::vector<int64_t> h((size_t)nvec + 1);
+    GBA_HIP(hipMemcpy(h.data(), fl.p, (size_t)(nvec + 1) * 8, hipMemcpyDeviceToHost));
+    const double total = (double)h[(size_t)nvec];
+    part[0] = 0;
+    for (int r = 1; r < nparts; r++) {
+        const int64_t target = (int64_t)(total * (double)r / (double)nparts);
+        int64_t k = std::lower_bound(h.begin(), h.end(), target) - h.begin();
+        if (k > nvec) k = nvec;
+        if (k < part[r - 1]) k = part[r - 1];
+        part[r] = k;
+    }
+    part[nparts] = nvec;
+    return GBA_SUCCESS;
+}

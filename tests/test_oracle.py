@@ -1,0 +1,150 @@
+"""CPU-only checks of the oracle: pinned against the reference's own known-answer
+demo output, then cross-checked against independent numpy/scipy computations."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from graphblas_amd import Matrix, Type, Sparsity
+from graphblas_amd import gen
+from oracle import oracle
+from util import assert_same, dense_of
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_gauss_demo_known_answers():
+    """The oracle's saxbit, dot3, saxpy3 (colscale/rowscale), dot4, saxpy4 and saxpy5
+    reproduce Demo/Output/gauss_demo.out (fixture tests/golden/gauss_demo_mxm.json)."""
+    want = json.load(open(os.path.join(GOLDEN, "gauss_demo_mxm.json")))
+    text = oracle.gauss_replay()
+    blocks = re.split(r"^(?=[AC] )", text, flags=re.M)
+    blocks = [b for b in blocks if b.strip()]
+    assert len(blocks) == len(want) == 7
+    entry = re.compile(r"\(\s*(-?\d+),\s*(-?\d+)\)|\s{6}\.\s{5}")
+    for blk, w in zip(blocks, want):
+        lines = blk.strip().splitlines()
+        assert lines[0] == w["name"]
+        for r in range(4):
+            row = [None if m.group(1) is None else [int(m.group(1)), int(m.group(2))]
+                   for m in entry.finditer(lines[1 + r].split(":", 1)[1])]
+            assert row == w["matrix"][r], (w["name"], r)
+    methods = ["bitmap saxpy", "dot3", "colscale", "rowscale", "dot4", "saxpy4", "saxpy5"]
+    for w, m in zip(want, methods):
+        assert m in w["burble"]
+
+
+def _rand_sparse(n, m, density, seed, ints=True):
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, m, density=density, random_state=rng, format="csr")
+    S.data = rng.integers(1, 9, len(S.data)).astype(np.float64) if ints else 1.0 - rng.random(len(S.data))
+    return S
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_saxpy3_matches_scipy(seed):
+    A = _rand_sparse(60, 50, 0.08, seed)
+    B = _rand_sparse(50, 70, 0.08, seed + 10)
+    # internal CSC vectors: use by_row=False so vectors are columns
+    Am, Bm = Matrix.from_scipy(A, by_row=False), Matrix.from_scipy(B, by_row=False)
+    C = oracle.saxpy3(None, False, False, Am, Bm, "PLUS_TIMES_FP64")
+    want = Matrix.from_scipy((A @ B).tocsc(), by_row=False)
+    assert_same(C, want, exact=True)
+
+
+def test_saxpy3_masks():
+    A = _rand_sparse(40, 40, 0.15, 5)
+    B = _rand_sparse(40, 40, 0.15, 6)
+    Mk = _rand_sparse(40, 40, 0.3, 7)
+    Am, Bm, Mm = (Matrix.from_scipy(X, by_row=False) for X in (A, B, Mk))
+    full = (A @ B).toarray()
+    pat = ((A != 0).astype(int) @ (B != 0).astype(int)).toarray() > 0
+    mpat = Mk.toarray() != 0
+    for comp in (False, True):
+        C = oracle.saxpy3(Mm, comp, True, Am, Bm, "PLUS_TIMES_FP64")
+        p, v = dense_of(C)
+        allow = mpat != comp
+        assert np.array_equal(p, pat & allow)
+        assert np.array_equal(v[p], full[p])
+
+
+def test_dot3_triangles():
+    G = gen.rmat(8, 8, seed=3, symmetric=True, drop_diagonal=True, values="ones")
+    L = gen.tril_strict(G)
+    C = oracle.dot3(L, True, L, L, "PLUS_PAIR_INT64")
+    S = L.to_scipy()
+    S.data[:] = 1
+    want = (S @ S.T).multiply(S)
+    r, c, v = C.coo()
+    assert v.sum() == int(want.sum())
+    assert C.nzombies == L.nvals - len(v)
+    W = sp.csr_matrix(want)
+    W.eliminate_zeros()
+    assert len(v) == W.nnz
+
+
+def test_flopcount_formula():
+    A = Matrix.from_scipy(_rand_sparse(50, 50, 0.1, 11), by_row=False)
+    B = Matrix.from_scipy(_rand_sparse(50, 30, 0.1, 12), by_row=False)
+    mw, fl = oracle.saxpy3_flopcount(None, False, A, B)
+    alen = np.diff(A.p)
+    per = np.array([(B.p[j + 1] - B.p[j]) + alen[B.i[B.p[j]:B.p[j + 1]]].sum() if B.p[j + 1] > B.p[j] else 0
+                    for j in range(B.vdim)])
+    assert mw == 0
+    assert np.array_equal(fl, np.concatenate([[0], np.cumsum(per)]))
+
+
+@pytest.mark.parametrize("desc", ["", "T0", "T1", "T0T1"])
+def test_mxm_spec_transposes(desc):
+    rng = np.random.default_rng(4)
+    A = _rand_sparse(12, 12, 0.3, 21)
+    B = _rand_sparse(12, 12, 0.3, 22)
+    Am, Bm = Matrix.from_scipy(A), Matrix.from_scipy(B)
+    Cm = Matrix.sparse_empty(12, 12, Type.FP64)
+    p, v = oracle.mxm_spec(Cm, None, None, "PLUS_TIMES_FP64", Am, Bm, desc)
+    X = A.T if "T0" in desc else A
+    Y = B.T if "T1" in desc else B
+    want = (X @ Y).toarray()
+    wp = ((X != 0).astype(int) @ (Y != 0).astype(int)).toarray() > 0
+    assert np.array_equal(p, wp)
+    assert np.array_equal(v[p], want[wp])
+
+
+def test_mxm_spec_accum_mask_replace():
+    A = _rand_sparse(10, 10, 0.3, 31)
+    B = _rand_sparse(10, 10, 0.3, 32)
+    C0 = _rand_sparse(10, 10, 0.4, 33)
+    Mk = _rand_sparse(10, 10, 0.5, 34)
+    Am, Bm, Cm, Mm = (Matrix.from_scipy(X) for X in (A, B, C0, Mk))
+    T = (A @ B).toarray()
+    tp = ((A != 0).astype(int) @ (B != 0).astype(int)).toarray() > 0
+    cp, cv = C0.toarray() != 0, C0.toarray()
+    mp = Mk.toarray() != 0
+    p, v = oracle.mxm_spec(Cm, Mm, "PLUS_FP64", "PLUS_TIMES_FP64", Am, Bm, "RSC")
+    zp = cp | tp
+    zv = np.where(cp & tp, cv + T, np.where(cp, cv, T))
+    allow = ~mp
+    assert np.array_equal(p, zp & allow)
+    assert np.array_equal(v[p], zv[p])
+    p2, v2 = oracle.mxm_spec(Cm, Mm, None, "PLUS_TIMES_FP64", Am, Bm, "S")
+    want_p = np.where(mp, tp, cp)
+    assert np.array_equal(p2, want_p)
+    assert np.array_equal(v2[p2], np.where(mp, T, cv)[p2])
+
+
+def test_semiring_arithmetic_corner_cases():
+    """Integer wrap, GB_idiv rules (Source/GB_math.h:27-260) and omit-NaN min."""
+    one = lambda t, a: Matrix(1, 1, t, Sparsity.SPARSE, True, p=[0, 1], i=[0], x=np.array([a]))
+    def prod(sr, t, a, b):
+        return oracle.saxpy3(None, False, False, one(t, a), one(t, b), sr).x[0]
+    assert prod("PLUS_TIMES_INT8", Type.INT8, 100, 3) == np.int8(300 - 256)
+    assert prod("PLUS_DIV_INT32", Type.INT32, 7, 0) == np.iinfo(np.int32).max
+    assert prod("PLUS_DIV_INT32", Type.INT32, -7, 0) == np.iinfo(np.int32).min
+    assert prod("PLUS_DIV_INT32", Type.INT32, 0, 0) == 0
+    assert prod("PLUS_DIV_UINT8", Type.UINT8, 9, 0) == 255
+    assert prod("PLUS_RDIV_INT16", Type.INT16, 2, 9) == 4
+    assert prod("PLUS_MIN_FP64", Type.FP64, np.nan, 2.0) == 2.0
+    assert prod("LOR_GT_FP32", Type.FP32, 2.0, 1.0) == True  # noqa: E712
