@@ -218,7 +218,7 @@ static gba_info dot_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask_c
         C->b = Cb.as<int8_t>(); Cb.release();
         C->x = Cx.release();
         C->nzombies = 0; C->type = c.ztype; C->sparsity = GBA_BITMAP; C->mem = GBA_MEM_DEVICE;
-        C->iso = false; C->jumbled = false;
+        C->iso = false; C->jumbled = false; C->is_csc = B->is_csc;
     } else {
         GBA_HIP(hipStreamSynchronize(st));
     }
@@ -350,7 +350,7 @@ static gba_info saxpy_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask
         C->b = Cb.as<int8_t>(); Cb.release();
         C->x = Cx.release();
         C->nzombies = 0; C->type = c.ztype; C->sparsity = GBA_BITMAP; C->mem = GBA_MEM_DEVICE;
-        C->iso = false; C->jumbled = false;
+        C->iso = false; C->jumbled = false; C->is_csc = B->is_csc;
     } else {
         GBA_HIP(hipStreamSynchronize(st));
     }
@@ -421,7 +421,7 @@ gba_info saxbit(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         C->b = Cb.as<int8_t>(); Cb.release();
         C->x = Cx.release();
         C->nzombies = 0; C->type = c.ztype; C->sparsity = GBA_BITMAP; C->mem = GBA_MEM_DEVICE;
-        C->iso = false; C->jumbled = false;
+        C->iso = false; C->jumbled = false; C->is_csc = B->is_csc;
         return GBA_SUCCESS;
     }
     GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxbit on device: A sparse or dense, B dense (got %d, %d)", A->sparsity, B->sparsity);

@@ -287,7 +287,7 @@ gba_info dot3(gba_matrix *C, const gba_matrix *M, bool Mask_struct, const gba_ma
     C->b = nullptr;
     C->nzombies = nz;
     C->type = c.ztype; C->sparsity = GBA_SPARSE; C->mem = GBA_MEM_DEVICE;
-    C->iso = false; C->jumbled = M->jumbled;
+    C->iso = false; C->jumbled = M->jumbled; C->is_csc = M->is_csc;
     return GBA_SUCCESS;
 }
 

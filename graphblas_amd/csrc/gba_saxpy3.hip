@@ -784,6 +784,7 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     C->sparsity = GBA_SPARSE;
     C->mem = GBA_MEM_DEVICE;
     C->iso = false;
+    C->is_csc = B->is_csc;
     C->jumbled = true;      // hash bins emit in table order (the reference leaves C jumbled too)
     if (mask_applied) *mask_applied = (M != nullptr);
     if (do_sort) GBA_OK(matrix_wait(C));

@@ -407,7 +407,7 @@ int orc_saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_str
     memset(C, 0, sizeof(*C));
     C->vlen = cvlen; C->vdim = cvdim; C->nvec = cvdim; C->nvals = Cp[cvdim];
     C->p = Cp; C->i = Ci; C->x = Cx; C->type = s->ztype; C->sparsity = GBA_SPARSE; C->mem = GBA_MEM_HOST;
-    C->jumbled = true; C->is_csc = true;
+    C->jumbled = true; C->is_csc = B->is_csc;
     return 0;
 }
 
@@ -499,7 +499,7 @@ int orc_dot3(gba_matrix *C, const gba_matrix *M, bool Mask_struct, const gba_mat
     memset(C, 0, sizeof(*C));
     C->vlen = M->vlen; C->vdim = M->vdim; C->nvec = nvec; C->nvals = mnz; C->nzombies = nzombies;
     C->p = Cp; C->i = Ci; C->x = Cx; C->type = s->ztype; C->sparsity = GBA_SPARSE; C->mem = GBA_MEM_HOST;
-    C->jumbled = M->jumbled; C->is_csc = true;
+    C->jumbled = M->jumbled; C->is_csc = M->is_csc;
     return 0;
 }
 
@@ -536,7 +536,7 @@ int orc_dot2(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struc
         }
     memset(C, 0, sizeof(*C));
     C->vlen = cvlen; C->vdim = cvdim; C->nvec = cvdim; C->nvals = nvals; C->b = Cb; C->x = Cx;
-    C->type = s->ztype; C->sparsity = GBA_BITMAP; C->mem = GBA_MEM_HOST; C->is_csc = true;
+    C->type = s->ztype; C->sparsity = GBA_BITMAP; C->mem = GBA_MEM_HOST; C->is_csc = B->is_csc;
     return 0;
 }
 
@@ -643,7 +643,7 @@ int orc_saxbit(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_str
     }
     memset(C, 0, sizeof(*C));
     C->vlen = cvlen; C->vdim = cvdim; C->nvec = cvdim; C->nvals = nvals; C->b = Cb; C->x = Cx;
-    C->type = s->ztype; C->sparsity = GBA_BITMAP; C->mem = GBA_MEM_HOST; C->is_csc = true;
+    C->type = s->ztype; C->sparsity = GBA_BITMAP; C->mem = GBA_MEM_HOST; C->is_csc = B->is_csc;
     return 0;
 }
 

@@ -1,0 +1,236 @@
+"""GPU parity for the front end: gba_mxm / gba_mxv / gba_vxm against the definition
+(Test/GB_spec_mxm.m restated in oracle.mxm_spec), and method selection against the
+dispatch the reference was observed to take."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from graphblas_amd import Matrix, DeviceMatrix, Type, Sparsity, Method, GrbError, Info, gen
+from graphblas_amd.binding import NP_TYPES
+from oracle import oracle
+from util import assert_dense_same
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rand(n, m, density, seed, t=Type.FP64, by_row=True, lo=1, hi=6):
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, m, density=density, random_state=rng, format="csr")
+    S.data = rng.integers(lo, hi, len(S.data)).astype(np.float64)
+    return Matrix.from_scipy(S, type=t, by_row=by_row)
+
+
+@pytest.mark.parametrize("desc", ["", "T0", "T1", "T0T1"])
+@pytest.mark.parametrize("fmt", ["rrr", "ccc", "rcr", "crc"])
+def test_mxm_all_transposes_and_formats(gba, desc, fmt):
+    """C = A*B for every descriptor transpose and CSR/CSC mix (Source/GB_AxB_meta.c:207-263)."""
+    n = 60
+    A = _rand(n, n, 0.1, 1, by_row=fmt[1] == "r")
+    B = _rand(n, n, 0.1, 2, by_row=fmt[2] == "r")
+    C0 = Matrix.sparse_empty(n, n, Type.FP64, by_row=fmt[0] == "r")
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    gba.mxm(dC, None, None, "PLUS_TIMES_FP64", dA, dB, desc)
+    p, v = oracle.mxm_spec(C0, None, None, "PLUS_TIMES_FP64", A, B, desc)
+    got = dC.to_host()
+    assert got.is_csc == C0.is_csc
+    assert_dense_same(got, p, v, exact=True, what=f"{desc}/{fmt}")
+
+
+@pytest.mark.parametrize("desc", ["S", "SC", "", "C", "RS", "RSC"])
+@pytest.mark.parametrize("mkind", ["sparse", "bitmap"])
+def test_mxm_masked_into_empty_C(gba, desc, mkind):
+    n = 80
+    A, B = _rand(n, n, 0.08, 3), _rand(n, n, 0.08, 4)
+    rng = np.random.default_rng(5)
+    if mkind == "sparse":
+        M = _rand(n, n, 0.2, 6, t=Type.INT8, lo=0, hi=2)
+    else:
+        M = Matrix.dense(rng.integers(0, 2, (n, n)).astype(np.int8), present=rng.random((n, n)) < 0.6)
+    C0 = Matrix.sparse_empty(n, n, Type.FP64)
+    dA, dB, dM, dC = A.to_device(), B.to_device(), M.to_device(), C0.to_device()
+    rep = gba.mxm(dC, dM, None, "PLUS_TIMES_FP64", dA, dB, desc)
+    p, v = oracle.mxm_spec(C0, M, None, "PLUS_TIMES_FP64", A, B, desc)
+    assert_dense_same(dC.to_host(), p, v, exact=True, what=f"{desc}/{mkind}")
+    assert rep.mask_applied
+
+
+def test_mxm_triangle_count_call(gba):
+    """C<L,struct> = L*L' exactly as LAGraph issues it: GrB_mxm(C, L, NULL, PLUS_PAIR_INT64, L, L, GrB_DESC_ST1)."""
+    G = gen.rmat(9, 16, seed=42, symmetric=True, drop_diagonal=True, values="ones", type=Type.INT64)
+    L = gen.tril_strict(G)
+    C0 = Matrix.sparse_empty(L.nrows, L.ncols, Type.INT64)
+    dL, dC = L.to_device(), C0.to_device()
+    rep = gba.mxm(dC, dL, None, "PLUS_PAIR_INT64", dL, dL, "ST1")
+    assert Method.NAMES[rep.method] == "dot3"
+    got = dC.to_host()
+    p, v = oracle.mxm_spec(C0, L, None, "PLUS_PAIR_INT64", L, L, "ST1")
+    assert_dense_same(got, p, v, exact=True)
+    S = L.to_scipy(); S.data[:] = 1
+    assert int(got.coo()[2].sum()) == int((S @ S.T).multiply(S).sum())
+
+
+@pytest.mark.parametrize("call", ["mxv", "mxv_T0", "vxm", "vxm_T1"])
+@pytest.mark.parametrize("wkind,accum", [("empty", None), ("full", "PLUS_FP32"), ("bitmap", "PLUS_FP32"), ("full", "MIN_FP32")])
+def test_mxv_vxm_dense_vectors(gba, call, wkind, accum):
+    """PageRank-shape products with a full input vector, every orientation the reference distinguishes."""
+    n = 300
+    A = _rand(n, n, 0.03, 7, t=Type.FP32)
+    rng = np.random.default_rng(8)
+    u = Matrix.full_vector(rng.integers(1, 5, n).astype(np.float32))
+    if wkind == "empty":
+        w0 = Matrix.sparse_vector(n, [], np.zeros(0, np.float32))
+    elif wkind == "full":
+        w0 = Matrix.full_vector(rng.integers(1, 5, n).astype(np.float32))
+    else:
+        w0 = Matrix.bitmap_vector(rng.integers(1, 5, n).astype(np.float32), rng.random(n) < 0.5)
+    dA, du, dw = A.to_device(), u.to_device(), w0.to_device()
+    sr = "PLUS_TIMES_FP32"
+    if call.startswith("mxv"):
+        desc = "T0" if call.endswith("T0") else ""
+        rep = gba.mxv(dw, None, accum, sr, dA, du, desc)
+        p, v = oracle.mxm_spec(w0, None, accum, sr, A, u, desc)
+    else:
+        desc = "T1" if call.endswith("T1") else ""
+        rep = gba.vxm(dw, None, accum, sr, du, dA, desc)
+        # w' = u'*A  ==  w = A'*u with the multiplier flipped (Source/GrB_vxm.c:56-72)
+        p, v = oracle.mxm_spec(w0, None, accum, sr, A, u, "", flipxy=True, A_tran=(desc != "T1"), B_tran=False)
+    assert_dense_same(dw.to_host(), p, v, exact=True, what=f"{call}/{wkind}/{accum}")
+    if wkind == "full" and accum == "PLUS_FP32":
+        assert rep.done_in_place
+        assert Method.NAMES[rep.method] in ("dot4", "saxpy4")
+
+
+def test_bfs_levels_match_reference_semantics(gba):
+    """Level-synchronous BFS with q<!pi,struct,replace> = q'*A, ANY_SECONDI_INT64: frontier patterns are
+    exact; every parent is a frontier neighbour (ANY may pick any of them)."""
+    G = gen.rmat(10, 8, seed=42, symmetric=True, drop_diagonal=True, values="ones", type=Type.BOOL)
+    n = G.nrows
+    S = G.to_scipy().astype(bool).tocsr()
+    dA = G.to_device()
+    src = int(np.argmax(np.diff(G.p)))
+    pi_b = np.zeros(n, np.int8); pi_x = np.zeros(n, np.int64)
+    pi_b[src] = 1; pi_x[src] = src
+    q = Matrix.sparse_vector(n, [src], np.array([src], np.int64))
+    visited = {src}
+    frontier = {src}
+    methods = []
+    for level in range(6):
+        dq = q.to_device()
+        dpi = Matrix.bitmap_vector(pi_x, pi_b).to_device()
+        dw = Matrix.sparse_vector(n, [], np.zeros(0, np.int64)).to_device()
+        rep = gba.vxm(dw, dpi, None, "ANY_SECONDI_INT64", dq, dA, "RSC")
+        methods.append(Method.NAMES[rep.method])
+        w = dw.to_host()
+        r, _, parents = w.coo()
+        want = set()
+        for k in frontier:
+            want.update(S.indices[S.indptr[k]:S.indptr[k + 1]].tolist())
+        want -= visited
+        assert set(r.tolist()) == want, f"level {level}"
+        for v_, p_ in zip(r, parents):
+            assert p_ in frontier and S[p_, v_]
+        if not want:
+            break
+        visited |= want; frontier = want
+        pi_b[r] = 1; pi_x[r] = parents
+        # keep the frontier sparse or bitmap as the reference would (bitmap once it is large)
+        if len(r) > n // 8:
+            b = np.zeros(n, np.int8); x = np.zeros(n, np.int64); b[r] = 1; x[r] = parents
+            q = Matrix.bitmap_vector(x, b)
+        else:
+            q = Matrix.sparse_vector(n, r, parents)
+    assert "saxpy3" in methods
+
+
+def test_sssp_relaxation_min_plus(gba):
+    """d<-> = d min.+ A with accum MIN, d full and aliased with the input: bit-exact with integer weights."""
+    A = gen.rmat(10, 8, seed=3, values="int", type=Type.FP64)
+    n = A.nrows
+    d = np.full(n, np.inf); d[0] = 0
+    S = A.to_scipy().tocsr()
+    dA = A.to_device()
+    for it in range(4):
+        dd = Matrix.full_vector(d).to_device()
+        rep = gba.vxm(dd, None, "MIN_FP64", "MIN_PLUS_FP64", dd, dA, None)
+        nd = d.copy()
+        for k in np.nonzero(np.isfinite(d))[0]:
+            cols = S.indices[S.indptr[k]:S.indptr[k + 1]]; w = S.data[S.indptr[k]:S.indptr[k + 1]]
+            np.minimum.at(nd, cols, d[k] + w)
+        got = dd.to_host()
+        assert got.sparsity == Sparsity.FULL
+        assert np.array_equal(got.x, nd), f"iteration {it}"
+        assert Method.NAMES[rep.method] == "saxbit"        # aliasing rules out the in-place saxpy4
+        d = nd
+
+
+def test_errors_mirror_grb_info(gba):
+    A = _rand(10, 12, 0.3, 9).to_device()
+    C = DeviceMatrix.empty(10, 10, Type.FP64)
+    with pytest.raises(GrbError) as e:
+        gba.mxm(C, None, None, "PLUS_TIMES_FP64", A, A, None)
+    assert e.value.info == Info.DIMENSION_MISMATCH
+    gba.mxm(C, None, None, "PLUS_TIMES_FP64", A, A, "T1")       # 10x12 * 12x10 is fine
+    B = _rand(10, 10, 0.3, 10, t=Type.INT32).to_device()
+    with pytest.raises(GrbError) as e:
+        gba.mxm(C, None, None, "PLUS_TIMES_FP64", B, B, None)   # needs a typecast: stays on the CPU library
+    assert e.value.info == Info.NOT_IMPLEMENTED
+
+
+def _operand(kind, n, A, rng, t):
+    dt = NP_TYPES[t]
+    if kind == "full":
+        return Matrix.full_vector(rng.integers(1, 5, n).astype(dt))
+    if kind == "bitmap":
+        return Matrix.bitmap_vector(rng.integers(1, 5, n).astype(dt), rng.random(n) < 0.5)
+    if kind == "sparse_small":
+        idx = rng.choice(n, max(n // 64, 1), replace=False)
+        return Matrix.sparse_vector(n, idx, rng.integers(1, 5, len(idx)).astype(dt))
+    if kind == "sparse_empty":
+        return Matrix.sparse_vector(n, [], np.zeros(0, dt))
+    raise ValueError(kind)
+
+
+def test_method_selection_matches_observed_dispatch(gba):
+    cases = json.load(open(os.path.join(GOLDEN, "dispatch_observed.json")))["cases"]
+    rng = np.random.default_rng(11)
+    for c in cases:
+        sr = gba.semiring(c["semiring"])
+        t = sr.xtype if c["semiring"].split("_")[1] not in ("SECONDI",) else Type.INT64
+        zt = sr.ztype
+        if c["call"] == "mxm_AA":
+            A = gen.rmat(12, 16, seed=42).to_device()
+            C = DeviceMatrix.empty(4096, 4096, Type.FP64)
+            rep = gba.mxm_select(C, None, None, sr, A, A, c["desc"])
+        elif c["call"] == "mxm_LLT":
+            G = gen.rmat(12, 16, seed=42, symmetric=True, drop_diagonal=True, values="ones", type=Type.INT64)
+            L = gen.tril_strict(G).to_device()
+            C = DeviceMatrix.empty(4096, 4096, Type.INT64)
+            rep = gba.mxm_select(C, L, None, sr, L, L, c["desc"])
+        else:
+            G = gen.rmat(12, 16, seed=42, symmetric=True, type=t if t != Type.INT64 else Type.INT64)
+            n = G.nrows
+            A = G.to_device()
+            w = _operand(c["w"], n, G, rng, zt).to_device()
+            u = w if c["u"] == "alias_w" else _operand(c["u"], n, G, rng, t).to_device()
+            mask = _operand(c["mask"], n, G, rng, Type.INT64).to_device() if c.get("mask") else None
+            fn = gba.lib.gba_mxv if c["call"] == "mxv" else gba.lib.gba_vxm
+            # select-only: same decision code, reached through gba_mxm_select with the operand order
+            # and flags GrB_mxv / GrB_vxm pass to GB_mxm (Source/GrB_mxv.c:57-66, GrB_vxm.c:63-72)
+            from graphblas_amd.host import _call3
+            rep = _select_vec(gba, c["call"], w, mask, c["accum"], sr, A, u, c["desc"])
+        assert Method.NAMES[rep.method] == c["method"], (c["name"], Method.NAMES[rep.method], c["burble"])
+        assert rep.done_in_place == c["in_place"], c["name"]
+        if "swapped" in c:
+            assert rep.swapped == c["swapped"], c["name"]
+
+
+def _select_vec(gba, call, w, mask, accum, sr, A, u, desc):
+    """Run the real mxv/vxm on copies (selection and execution share one code path) and report the method."""
+    wc = w.to_host().to_device()
+    if call == "mxv":
+        return gba.mxv(wc, mask, accum, sr, A, u if u is not w else wc, desc)
+    return gba.vxm(wc, mask, accum, sr, u if u is not w else wc, A, desc)

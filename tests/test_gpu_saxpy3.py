@@ -1,0 +1,190 @@
+"""GPU parity: gba_AxB_saxpy3 / flopcount / cumsum against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from graphblas_amd import Matrix, Type, Sparsity, gen
+from oracle import oracle
+from util import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def _csc(S, t=Type.FP64):
+    return Matrix.from_scipy(S, type=t, by_row=False)
+
+
+def _rand(n, m, density, seed, lo=1, hi=9):
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, m, density=density, random_state=rng, format="csc")
+    S.data = rng.integers(lo, hi, len(S.data)).astype(np.float64)
+    return S
+
+
+def _run(gba, A, B, sr, M=None, comp=False, struct=True):
+    dA, dB = A.to_device(), B.to_device()
+    dM = M.to_device() if M is not None else None
+    out, rep, applied = gba.AxB_saxpy3(dM, comp, struct, dA, dB, sr)
+    got = out.to_host()
+    for d in (dA, dB, dM, out):
+        if d is not None:
+            d.free()
+    return got, rep, applied
+
+
+def test_cumsum(gba):
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 5, 2048, 2049, 100000, 3_000_001):
+        c = rng.integers(0, 1000, n)
+        got = gba.cumsum(c)
+        assert np.array_equal(got, np.concatenate([[0], np.cumsum(c)]).astype(np.int64)), n
+
+
+@pytest.mark.parametrize("scale,ef", [(8, 8), (10, 16)])
+def test_rmat_plus_times_fp64(gba, scale, ef):
+    A = gen.rmat(scale, ef, seed=42, by_row=False)
+    got, rep, _ = _run(gba, A, A, "PLUS_TIMES_FP64")
+    want = oracle.saxpy3(None, False, False, A, A, "PLUS_TIMES_FP64")
+    # summation order differs (atomics): the reference's own 64*eps rule, scaled by the
+    # longest sum (number of terms per entry is bounded by the row length)
+    assert_same(got, want, exact=False, rtol_scale=8)
+
+
+def test_rmat_integer_valued_is_bit_exact(gba):
+    A = gen.rmat(10, 16, seed=7, by_row=False, values="int")
+    got, _, _ = _run(gba, A, A, "PLUS_TIMES_FP64")
+    want = oracle.saxpy3(None, False, False, A, A, "PLUS_TIMES_FP64")
+    assert_same(got, want, exact=True)          # all partial sums are integers < 2^53
+
+
+def test_low_degree_erdos_renyi_hash_bins(gba):
+    A = gen.erdos_renyi(5000, 12000, seed=3, by_row=False, values="int")
+    got, _, _ = _run(gba, A, A, "PLUS_TIMES_FP64")
+    assert_same(got, oracle.saxpy3(None, False, False, A, A, "PLUS_TIMES_FP64"), exact=True)
+
+
+def test_every_bin_including_global(gba):
+    """A with a few very heavy rows: outputs land in wave, block and global bins."""
+    n = 40000
+    rng = np.random.default_rng(5)
+    rows = [rng.integers(0, n, 60000), np.zeros(30000, np.int64), rng.integers(0, n, 30000)]
+    cols = [rng.integers(0, n, 60000), rng.integers(0, n, 30000), np.ones(30000, np.int64)]
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    S = sp.coo_matrix((rng.integers(1, 5, len(r)).astype(np.float64), (r, c)), shape=(n, n)).tocsc()
+    S.sum_duplicates()
+    A = _csc(S)
+    got, _, _ = _run(gba, A, A, "PLUS_TIMES_FP64")
+    want = oracle.saxpy3(None, False, False, A, A, "PLUS_TIMES_FP64")
+    assert want.nvals > 100000
+    assert_same(got, want, exact=True)
+
+
+def test_empty_and_ragged(gba):
+    E = _csc(sp.csc_matrix((50, 50)))
+    got, _, _ = _run(gba, E, E, "PLUS_TIMES_FP64")
+    assert got.nvals == 0 and len(got.p) == 51
+    A = _csc(_rand(30, 0, 0.0, 1))            # 30 x 0
+    B = _csc(sp.csc_matrix((0, 20)))          # 0 x 20
+    got, _, _ = _run(gba, A, B, "PLUS_TIMES_FP64")
+    assert got.nvals == 0 and got.vlen == 30 and got.vdim == 20
+    A = _csc(_rand(17, 33, 0.2, 2)); B = _csc(_rand(33, 5, 0.3, 3))
+    got, _, _ = _run(gba, A, B, "PLUS_TIMES_FP64")
+    assert_same(got, oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64"), exact=True)
+
+
+SEMIRINGS = [
+    ("PLUS_TIMES_INT32", Type.INT32), ("PLUS_TIMES_INT8", Type.INT8), ("PLUS_TIMES_UINT16", Type.UINT16),
+    ("PLUS_TIMES_INT64", Type.INT64), ("PLUS_TIMES_FP32", Type.FP32),
+    ("MIN_PLUS_FP64", Type.FP64), ("MAX_PLUS_INT32", Type.INT32), ("MIN_MAX_UINT8", Type.UINT8),
+    ("MIN_FIRST_INT16", Type.INT16), ("MAX_SECOND_FP32", Type.FP32), ("TIMES_PLUS_INT32", Type.INT32),
+    ("TIMES_MIN_FP64", Type.FP64), ("PLUS_PAIR_INT64", Type.INT64), ("PLUS_MINUS_INT32", Type.INT32),
+    ("PLUS_RMINUS_INT64", Type.INT64), ("PLUS_DIV_INT32", Type.INT32), ("PLUS_RDIV_UINT8", Type.UINT8),
+    ("PLUS_ISGT_INT32", Type.INT32), ("PLUS_LOR_FP64", Type.FP64), ("MAX_LAND_INT8", Type.INT8),
+    ("LOR_LAND_BOOL", Type.BOOL), ("LXOR_LOR_BOOL", Type.BOOL), ("EQ_LXOR_BOOL", Type.BOOL), ("LAND_EQ_BOOL", Type.BOOL),
+    ("LOR_GT_INT32", Type.INT32), ("LXOR_LE_FP64", Type.FP64), ("LAND_NE_UINT8", Type.UINT8), ("EQ_EQ_INT16", Type.INT16),
+    ("BOR_BAND_UINT8", Type.UINT8), ("BXOR_BOR_UINT32", Type.UINT32), ("BXNOR_BXOR_UINT64", Type.UINT64),
+    ("BAND_BOR_UINT16", Type.UINT16),
+    ("MIN_FIRSTI_INT64", Type.INT64), ("MAX_FIRSTJ_INT32", Type.INT32), ("PLUS_SECONDJ_INT64", Type.INT64),
+    ("MIN_SECONDI1_INT64", Type.INT64), ("TIMES_FIRSTI1_INT32", Type.INT32),
+]
+
+
+@pytest.mark.parametrize("sr,t", SEMIRINGS)
+def test_builtin_semirings_bit_exact(gba, sr, t):
+    """Integer, boolean, MIN/MAX, PAIR, bitwise and positional semirings agree bit for bit.
+    fp32 PLUS_TIMES uses small integers, so every partial sum is exact."""
+    S = _rand(300, 300, 0.03, 17, lo=0, hi=4)
+    S.data[::7] = 0          # explicit zeros exercise LOR/LAND/comparators and division by zero
+    A = _csc(S, t)
+    got, _, _ = _run(gba, A, A, sr)
+    assert_same(got, oracle.saxpy3(None, False, False, A, A, sr), exact=True, what=sr)
+
+
+def test_any_monoid_is_a_valid_choice(gba):
+    """ANY takes whichever product arrives first (the reference skips value checks for it,
+    Test/GB_spec_compare.m:17-22): pattern must match; each value must be one of the products."""
+    S = _rand(200, 200, 0.05, 23)
+    A = _csc(S, Type.INT64)
+    got, _, _ = _run(gba, A, A, "ANY_SECONDI_INT64")
+    want = oracle.saxpy3(None, False, False, A, A, "ANY_SECONDI_INT64")
+    assert_same(got, want, check_values=False)
+    r, c, v = got.coo()
+    pat = (S != 0).tocsr()
+    for i, j, k in zip(r[:2000], c[:2000], v[:2000]):
+        assert pat[i, k] and pat[k, j]
+
+
+@pytest.mark.parametrize("comp", [False, True])
+@pytest.mark.parametrize("struct", [True, False])
+@pytest.mark.parametrize("mkind", ["sparse", "bitmap", "full"])
+def test_masks(gba, comp, struct, mkind):
+    S = _rand(400, 400, 0.02, 31)
+    A = _csc(S)
+    rng = np.random.default_rng(9)
+    mv = rng.integers(0, 2, (400, 400)).astype(np.int8)      # valued mask: zeros are "false"
+    if mkind == "sparse":
+        Ms = sp.random(400, 400, density=0.1, random_state=rng, format="csc")
+        Ms.data = rng.integers(0, 2, len(Ms.data)).astype(np.float64)
+        M = Matrix.from_scipy(Ms, type=Type.INT8, by_row=False)
+    elif mkind == "bitmap":
+        M = Matrix.dense(mv, present=rng.random((400, 400)) < 0.5, by_row=False)
+    else:
+        M = Matrix.dense(mv, by_row=False)
+    got, _, applied = _run(gba, A, A, "PLUS_TIMES_FP64", M=M, comp=comp, struct=struct)
+    assert applied
+    assert_same(got, oracle.saxpy3(M, comp, struct, A, A, "PLUS_TIMES_FP64"), exact=True)
+
+
+@pytest.mark.parametrize("mask", [None, "M", "notM", "dense"])
+def test_flopcount(gba, mask):
+    A = gen.rmat(9, 8, seed=11, by_row=False)
+    rng = np.random.default_rng(2)
+    M, comp = None, False
+    if mask in ("M", "notM"):
+        Ms = sp.random(512, 512, density=0.02, random_state=rng, format="csc")
+        M = Matrix.from_scipy(Ms, by_row=False)
+        comp = mask == "notM"
+    elif mask == "dense":
+        M = Matrix.dense(np.ones((512, 512), np.int8), by_row=False)
+    dA = A.to_device()
+    dM = M.to_device() if M is not None else None
+    mw, fl = gba.AxB_saxpy3_flopcount(dM, comp, dA, dA)
+    omw, ofl = oracle.saxpy3_flopcount(M, comp, A, A)
+    assert mw == omw
+    assert np.array_equal(fl, ofl)
+
+
+def test_checksum_property_large(gba):
+    """Size-independent check at a scale the oracle would take long on: for PLUS_TIMES with
+    integer values, sum(C) == sum_k colsum_A(k) * rowsum_B(k), exactly (all sums < 2^53)."""
+    A = gen.rmat(14, 16, seed=42, by_row=False, values="int")
+    got, rep, _ = _run(gba, A, A, "PLUS_TIMES_FP64")
+    S = sp.csc_matrix((A.x, A.i, A.p), shape=(A.vlen, A.vdim))
+    colsum = np.asarray(S.sum(axis=0)).ravel()
+    rowsum = np.asarray(S.sum(axis=1)).ravel()
+    assert float(got.x.sum()) == float((colsum * rowsum).sum())
+    assert np.all(np.diff(got.p) >= 0) and got.p[-1] == len(got.i)
+    # no duplicate index inside a vector
+    vec = np.repeat(np.arange(got.vdim), np.diff(got.p))
+    key = vec * got.vlen + got.i
+    assert len(np.unique(key)) == len(key)
