@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SpGEMM C = A*A, PLUS_TIMES_FP64, Graph500 RMAT (edge factor 16, seed 42),
+through gba_mxm on 1..8 MI355X.
+
+One step = one whole C = A*A.  C of RMAT-22 (~7e10 entries, ~1.2 TB with 64-bit indices) does not
+fit any GPU, so a rank computes its rows in flop-balanced row chunks, C(I,:) = A(I,:)*A, and
+releases each chunk's C before the next (every entry of C is produced, exactly once per step).
+With N > 1 ranks the rows of A and C are 1-D partitioned by flop count; each step starts with the
+all-gather of the row blocks of A (RCCL) that every rank needs as the right-hand operand.
+
+Prints ONE JSON line (rank 0).  value = 2 * multiply-adds / time, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E nominal
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scale", type=int, default=int(os.environ.get("GBA_BENCH_SCALE", "22")))
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--chunk-flops", type=float, default=6e9, help="max multiply-adds per row chunk")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-flops", type=float, default=2.5e9, help="multiply-adds in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def row_flops(A):
+    """multiply-adds per row of A*A for a CSR host Matrix: sum over k in A(i,:) of nnz A(k,:)."""
+    deg = np.diff(A.p)
+    per_entry = deg[A.i]
+    cs = np.concatenate([[0], np.cumsum(per_entry)])
+    return cs[A.p[1:]] - cs[A.p[:-1]]
+
+
+def split_by_flops(prefix, lo, hi, nparts):
+    """boundaries of nparts contiguous pieces of rows [lo,hi) with ~equal flops (prefix = cumsum of row flops)."""
+    base, total = prefix[lo], prefix[hi] - prefix[lo]
+    cuts = [lo]
+    for r in range(1, nparts):
+        k = int(np.searchsorted(prefix, base + total * r / nparts, side="left"))
+        cuts.append(min(max(k, cuts[-1]), hi))
+    cuts.append(hi)
+    return cuts
+
+
+def chunks_by_flops(prefix, lo, hi, max_flops):
+    out, start = [], lo
+    while start < hi:
+        k = int(np.searchsorted(prefix, prefix[start] + max_flops, side="right")) - 1
+        k = min(max(k, start + 1), hi)
+        out.append((start, k))
+        start = k
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import graphblas_amd as g
+    from graphblas_amd import gen, Type, DeviceMatrix
+    from graphblas_amd.binding import gba_matrix
+    g.init(local_rank)
+
+    t0 = time.time()
+    A = gen.rmat(args.scale, args.edge_factor, seed=42, type=Type.FP64)      # CSR, values uniform (0,1]
+    n, nnzA = A.nrows, A.nvals
+    rf = row_flops(A)
+    prefix = np.concatenate([[0], np.cumsum(rf)]).astype(np.int64)
+    total_madds = int(prefix[-1])
+    gen_s = time.time() - t0
+
+    # 1-D partition of rows over ranks, balanced by flops (the same count saxpy3 bins by)
+    part = split_by_flops(prefix, 0, n, world)
+    my_lo, my_hi = part[rank], part[rank + 1]
+    my_chunks = chunks_by_flops(prefix, my_lo, my_hi, args.chunk_flops)
+
+    # device copies.  Right-hand operand: full A on every rank, held in torch tensors so that RCCL can fill them.
+    dev = torch.device("cuda", local_rank)
+    Bp = torch.from_numpy(A.p).to(dev)
+    Bi = torch.empty(nnzA, dtype=torch.int64, device=dev)
+    Bx = torch.empty(nnzA, dtype=torch.float64, device=dev)
+    e_lo, e_hi = int(A.p[my_lo]), int(A.p[my_hi])
+    my_i = torch.from_numpy(A.i[e_lo:e_hi]).to(dev)
+    my_x = torch.from_numpy(A.x[e_lo:e_hi]).to(dev)
+    counts = [int(A.p[part[r + 1]] - A.p[part[r]]) for r in range(world)]
+    offs = [int(A.p[part[r]]) for r in range(world)]
+    pad = max(counts) if world > 1 else 0
+    if world > 1:
+        gi = [torch.empty(pad, dtype=torch.int64, device=dev) for _ in range(world)]
+        gx = [torch.empty(pad, dtype=torch.float64, device=dev) for _ in range(world)]
+        si = torch.zeros(pad, dtype=torch.int64, device=dev); si[: counts[rank]] = my_i
+        sx = torch.zeros(pad, dtype=torch.float64, device=dev); sx[: counts[rank]] = my_x
+
+    def exchange():
+        """all-gather of the row blocks of A into the full right-hand operand (no-op on one GPU)."""
+        if world == 1:
+            Bi.copy_(my_i); Bx.copy_(my_x)
+            return
+        dist.all_gather(gi, si)
+        dist.all_gather(gx, sx)
+        for r in range(world):
+            Bi[offs[r]: offs[r] + counts[r]] = gi[r][: counts[r]]
+            Bx[offs[r]: offs[r] + counts[r]] = gx[r][: counts[r]]
+
+    def view_rows(lo, hi):
+        m = gba_matrix()
+        m.vlen, m.vdim, m.nvec = n, hi - lo, hi - lo
+        m.nvals = int(A.p[hi] - A.p[lo])
+        m.p, m.i, m.x = Bp.data_ptr() + 8 * lo, Bi.data_ptr(), Bx.data_ptr()
+        m.type, m.sparsity, m.mem, m.is_csc = Type.FP64, g.Sparsity.SPARSE, 0, False
+        return DeviceMatrix(m, owns=False)
+
+    Bfull = view_rows(0, n)
+    sr = g.semiring("PLUS_TIMES_FP64")
+    stats = {"phase_ms": np.zeros(8), "cnz": 0, "bins": np.zeros(4, np.int64), "bin_cnz": np.zeros(4, np.int64),
+             "bin_bnz": np.zeros(4, np.int64), "launches": 0}
+
+    def step(collect):
+        exchange()
+        torch.cuda.synchronize()
+        for lo, hi in my_chunks:
+            Cc = DeviceMatrix.empty(hi - lo, n, Type.FP64)
+            rep = g.mxm(Cc, None, None, sr, view_rows(lo, hi), Bfull, None)
+            if collect:
+                stats["phase_ms"] += np.array(rep.phase_ms[:])
+                stats["cnz"] += rep.cnz
+                stats["bins"] += np.array(rep.bin_vectors[:])
+                stats["bin_cnz"] += np.array(rep.bin_cnz[:])
+                stats["bin_bnz"] += np.array(rep.bin_bnz[:])
+                stats["launches"] += 1
+            Cc.free()
+        g.sync()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        agg = torch.tensor([stats["cnz"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(agg)
+        cnz_all = int(agg.item()) // max(args.steps, 1)
+    else:
+        cnz_all = stats["cnz"] // max(args.steps, 1)
+
+    if rank == 0:
+        sec_per_step = elapsed / args.steps
+        gflops = 2.0 * total_madds / sec_per_step / 1e9
+        w_i, w_v = 8, 8                                  # int64 indices and fp64 values, as handed over by the API
+        compulsory = (2 * nnzA + cnz_all) * (w_i + w_v) + 3 * (n + 1) * 8
+        # dominant kernel of rank 0: the numeric kernel with the largest accumulated time
+        names = ["num_wave_kernel", "num_block_kernel<4096>", "num_block_kernel<8192>", "num_global_kernel"]
+        k = int(np.argmax(stats["phase_ms"][3:7]))
+        launches = max(stats["launches"], 1)
+        k_ms = stats["phase_ms"][3 + k] / launches
+        # algorithmic bytes of that kernel per launch: its B vectors and its C entries once, A once
+        k_bytes = (stats["bin_bnz"][k] * (w_i + w_v) + stats["bin_cnz"][k] * (w_i + w_v)) / launches + nnzA * (w_i + w_v)
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "SpGEMM semiring GFLOP/s, RMAT C=A*A PLUS_TIMES_FP64",
+            "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"RMAT-{args.scale} ef={args.edge_factor} seed=42 C=A*A via gba_mxm (CSR, int64 indices), "
+                                   f"{len(my_chunks)} row chunks on rank 0, C released per chunk",
+                       "n": n, "nnz_A": nnzA, "multiply_adds": total_madds, "nnz_C": cnz_all,
+                       "parallelism": f"rowblock{world}" + ("+allgatherB" if world > 1 else "")},
+            "hbm_GBps_compulsory": round(compulsory / sec_per_step / 1e9, 2),
+            "phase_ms_per_step_rank0": [round(float(x) / args.steps, 3) for x in stats["phase_ms"]],
+            "numeric_bin_vectors_rank0": [int(x) // max(args.steps, 1) for x in stats["bins"]],
+            "roofline": {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "avg_launch_ms": round(float(k_ms), 3), "algorithmic_bytes_per_launch": int(k_bytes)},
+            "generate_s": round(gen_s, 1),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(A, rf, args.cpu_flops)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(A, rf, target_madds):
+    """The CPU oracle (restatement of the reference's coarse Gustavson saxpy3, OpenMP) on a bounded
+    sample of the same workload: every stride-th row of A times the whole A."""
+    from graphblas_amd import Matrix, Type
+    from oracle import oracle
+    n = A.nrows
+    total = float(rf.sum())
+    stride = max(int(round(total / max(target_madds, 1.0))), 1)
+    rows = np.arange(0, n, stride)
+    lens = np.diff(A.p)[rows]
+    p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = np.concatenate([np.arange(A.p[r], A.p[r + 1]) for r in rows]) if len(rows) else np.zeros(0, np.int64)
+    As = Matrix(n, len(rows), Type.FP64, A.sparsity, False, p=p, i=A.i[idx], x=A.x[idx])
+    madds = int(rf[rows].sum())
+    t = time.perf_counter()
+    C = oracle.saxpy3(None, False, False, A, As, "PLUS_TIMES_FP64")      # internal operands: (A_I, B_I) = (A, sample rows)
+    dt = time.perf_counter() - t
+    return {"value": round(2.0 * madds / dt / 1e9, 4), "unit": "GFLOP/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"rows 0,{stride},{2 * stride},... of A ({len(rows)} rows, {madds} multiply-adds, "
+                      f"{100.0 * madds / total:.2f}% of the job, nnz(C sample)={C.nvals}) times the whole A; {dt:.1f} s",
+            "seconds": round(dt, 2)}
+
+
+if __name__ == "__main__":
+    main()

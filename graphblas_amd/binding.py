@@ -102,7 +102,9 @@ class gba_descriptor(C.Structure):
 class gba_report(C.Structure):
     _fields_ = [("method", C.c_int32), ("swapped", C.c_int32), ("mask_applied", C.c_int32),
                 ("done_in_place", C.c_int32), ("a_transposed", C.c_int32), ("b_transposed", C.c_int32),
-                ("flops", C.c_int64), ("kernel_ms", C.c_double)]
+                ("flops", C.c_int64), ("kernel_ms", C.c_double), ("phase_ms", C.c_double * 8),
+                ("bin_vectors", C.c_int64 * 4), ("bin_cnz", C.c_int64 * 4), ("bin_bnz", C.c_int64 * 4),
+                ("cnz", C.c_int64)]
 
 
 class GrbError(RuntimeError):

@@ -251,6 +251,23 @@ static gba_info build_bins(int64_t nvec, const int64_t *work, bool ptr_diff, Bin
     return GBA_SUCCESS;
 }
 
+// totals of nnz C(:,j) and nnz B(:,j) over one bin (reporting only)
+__global__ void __launch_bounds__(256)
+bin_stats_kernel(int64_t nlist, const int64_t *__restrict__ list, const int64_t *__restrict__ Cp,
+                 const int64_t *__restrict__ Bp, unsigned long long *__restrict__ out /* [2] */) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0, b = 0;
+    for (; idx < nlist; idx += stride) {
+        const int64_t j = list[idx];
+        c += (unsigned long long)(Cp[j + 1] - Cp[j]);
+        b += (unsigned long long)(Bp[j + 1] - Bp[j]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { c += __shfl_down(c, d, 64); b += __shfl_down(b, d, 64); }
+    if ((threadIdx.x & 63) == 0) { if (c) atomicAdd(&out[0], c); if (b) atomicAdd(&out[1], b); }
+}
+
 // ------------------------------------------------------------- LDS hashing --
 static constexpr int32_t HASH_EMPTY = -1;
 
@@ -610,10 +627,28 @@ template <class K> static gba_info set_lds(K kernel, size_t bytes) {
     return GBA_SUCCESS;
 }
 
+// HIP events at phase boundaries on the library stream
+struct PhaseClock {
+    static constexpr int MAXEV = 12;
+    hipEvent_t ev[MAXEV];
+    int n = 0;
+    bool on;
+    explicit PhaseClock(bool enable) : on(enable) { if (on) for (int k = 0; k < MAXEV; k++) hipEventCreate(&ev[k]); }
+    ~PhaseClock() { if (on) for (int k = 0; k < MAXEV; k++) hipEventDestroy(ev[k]); }
+    int mark() { if (!on || n >= MAXEV) return -1; hipEventRecord(ev[n], ctx().stream); return n++; }
+    double ms(int a, int b) {
+        if (!on || a < 0 || b < 0) return 0.0;
+        hipEventSynchronize(ev[b]);
+        float f = 0.f; hipEventElapsedTime(&f, ev[a], ev[b]); return (double)f;
+    }
+};
+
 struct Saxpy3Plan {
     SpView A, B; MaskView M; int lpa; int64_t cvlen, nvec;
     Bins sym, num;
     int64_t *Cp, *Ci; void *Cx;
+    PhaseClock *clock = nullptr;
+    int ev_num[5] = {-1, -1, -1, -1, -1};   // before wave, blk1, blk2, global, after global
 };
 
 template <class S>
@@ -622,10 +657,13 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
     hipStream_t st = ctx().stream;
     Z *Cx = reinterpret_cast<Z *>(P.Cx);
     const Bins &nb = P.num;
+    auto mark = [&](int slot) { if (P.clock) P.ev_num[slot] = P.clock->mark(); };
+    mark(0);
     if (nb.count[BIN_WAVE] > 0) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(num_wave_kernel<S>), dim3((unsigned)ceil_div(nb.count[BIN_WAVE], 4)), dim3(256), 0, st,
                            sr, nb.count[BIN_WAVE], nb.list(BIN_WAVE), P.A, P.B, P.M, P.lpa, P.Cp, P.Ci, Cx);
     }
+    mark(1);
     if (nb.count[BIN_BLK1] > 0) {
         auto k = num_block_kernel<S, NUM_BLK1_SLOTS, NUM_BLK1_THREADS>;
         const size_t lds = (size_t)NUM_BLK1_SLOTS * (sizeof(ACC) + 4);
@@ -633,6 +671,7 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         hipLaunchKernelGGL(k, dim3((unsigned)nb.count[BIN_BLK1]), dim3(NUM_BLK1_THREADS), lds, st,
                            sr, nb.count[BIN_BLK1], nb.list(BIN_BLK1), P.A, P.B, P.M, P.lpa, P.Cp, P.Ci, Cx);
     }
+    mark(2);
     if (nb.count[BIN_BLK2] > 0) {
         auto k = num_block_kernel<S, NUM_BLK2_SLOTS, NUM_BLK2_THREADS>;
         const size_t lds = (size_t)NUM_BLK2_SLOTS * (sizeof(ACC) + 4);
@@ -641,6 +680,7 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
                            sr, nb.count[BIN_BLK2], nb.list(BIN_BLK2), P.A, P.B, P.M, P.lpa, P.Cp, P.Ci, Cx);
     }
     GBA_HIP(hipGetLastError());
+    mark(3);
     if (nb.count[BIN_GLOBAL] > 0) {
         const int64_t nf = (P.cvlen + 63) >> 6, ns = (nf + 63) >> 6;
         const size_t per_block = (size_t)P.cvlen * sizeof(ACC) + (size_t)(nf + ns) * 8;
@@ -668,7 +708,10 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
                            Hx.as<ACC>(), Hf.as<uint64_t>(), Hs.as<uint64_t>(), next.as<unsigned long long>(),
                            P.Cp, P.Ci, Cx);
         GBA_HIP(hipGetLastError());
+        mark(4);
         GBA_HIP(hipStreamSynchronize(st));      // workspaces are released on return
+    } else {
+        mark(4);
     }
     return GBA_SUCCESS;
 }
@@ -735,18 +778,22 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     P.nvec = B->nvec;
     const int64_t nvec = P.nvec;
 
-    // phase 0: flop count per vector (kept un-summed for binning)
-    DevBuf vflops; GBA_OK(vflops.alloc((size_t)(nvec + 1) * 8));
-    int64_t Mwork = 0;
-    GBA_OK(saxpy3_flopcount(&Mwork, vflops.as<int64_t>(), M, Mask_comp, A, B));
-    GBA_OK(build_bins(nvec, vflops.as<int64_t>(), false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, SYM_BLK2_MAX}, &P.sym));
+    PhaseClock clock(rep != nullptr);
+    P.clock = rep ? &clock : nullptr;
+    const int e0 = clock.mark();
 
-    KernelTimer timer(rep != nullptr);
+    // phase 0: flop count per vector (kept un-summed for binning).  The un-masked count is an upper
+    // bound on nnz C(:,j) whatever the mask does, which is what sizes the hash tables.
+    DevBuf vflops; GBA_OK(vflops.alloc((size_t)(nvec + 1) * 8));
+    GBA_OK(saxpy3_flopcount(nullptr, vflops.as<int64_t>(), nullptr, false, A, B));
+    GBA_OK(build_bins(nvec, vflops.as<int64_t>(), false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, SYM_BLK2_MAX}, &P.sym));
+    const int e1 = clock.mark();
 
     // phase 1: symbolic, cnt[j] = nnz C(:,j), written into the future C->p
     DevBuf Cp; GBA_OK(Cp.alloc((size_t)(nvec + 1) * 8));
     GBA_HIP(hipMemsetAsync(Cp.p, 0, (size_t)(nvec + 1) * 8, st));
     GBA_OK(run_symbolic(P, Cp.as<int64_t>()));
+    const int e2 = clock.mark();
 
     // numeric bins use the exact counts, taken before the prefix sum
     GBA_OK(build_bins(nvec, Cp.as<int64_t>(), false, BinLimits{NUM_WAVE_MAX, NUM_BLK1_MAX, NUM_BLK2_MAX}, &P.num));
@@ -768,9 +815,32 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     }
     GBA_HIP(hipStreamSynchronize(st));
     if (rep) {
-        rep->kernel_ms = timer.stop_ms();
-        int64_t tot = 0;
-        (void)tot;
+        const int e4 = clock.mark();
+        rep->phase_ms[0] = clock.ms(e0, e1);
+        rep->phase_ms[1] = clock.ms(e1, e2);
+        if (cnz > 0) {
+            rep->phase_ms[2] = clock.ms(e2, P.ev_num[0]);
+            for (int b = 0; b < 4; b++) rep->phase_ms[3 + b] = clock.ms(P.ev_num[b], P.ev_num[b + 1]);
+        } else {
+            rep->phase_ms[2] = clock.ms(e2, e4);
+        }
+        rep->kernel_ms = clock.ms(e0, e4);
+        rep->cnz = cnz;
+        rep->bin_vectors[0] = P.num.count[BIN_WAVE]; rep->bin_vectors[1] = P.num.count[BIN_BLK1];
+        rep->bin_vectors[2] = P.num.count[BIN_BLK2]; rep->bin_vectors[3] = P.num.count[BIN_GLOBAL];
+        DevBuf bs; GBA_OK(bs.alloc(8 * 8));
+        GBA_HIP(hipMemsetAsync(bs.p, 0, 64, st));
+        for (int b = 0; b < 4; b++) {
+            const int64_t cntb = P.num.count[BIN_WAVE + b];
+            if (cntb == 0) continue;
+            int64_t blocks = ceil_div(cntb, 256); if (blocks > 1024) blocks = 1024;
+            hipLaunchKernelGGL(bin_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cntb, P.num.list(BIN_WAVE + b),
+                               Cp.as<int64_t>(), B->p, bs.as<unsigned long long>() + 2 * b);
+        }
+        unsigned long long hs[8];
+        GBA_HIP(hipMemcpyAsync(hs, bs.p, 64, hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipStreamSynchronize(st));
+        for (int b = 0; b < 4; b++) { rep->bin_cnz[b] = (int64_t)hs[2 * b]; rep->bin_bnz[b] = (int64_t)hs[2 * b + 1]; }
     }
 
     C->vlen = A->vlen; C->vdim = B->vdim; C->nvec = nvec; C->nvals = cnz;

@@ -165,7 +165,15 @@ typedef struct gba_report {
     int32_t a_transposed;   /* an explicit transpose of A was materialised      */
     int32_t b_transposed;
     int64_t flops;          /* multiply-adds counted by the flop count, or -1   */
-    double  kernel_ms;      /* device time of the numeric kernels (HIP events)  */
+    double  kernel_ms;      /* device time of the whole method (HIP events on the library stream) */
+    /* saxpy3 only: device time per phase, HIP events on the library stream.
+     * [0] flop count + binning  [1] symbolic  [2] numeric binning + cumsum + allocation
+     * [3] numeric wave bin  [4] numeric block bin 1  [5] numeric block bin 2  [6] numeric global bin  [7] sort */
+    double  phase_ms[8];
+    int64_t bin_vectors[4]; /* saxpy3 numeric: vectors routed to wave / block1 / block2 / global bins */
+    int64_t bin_cnz[4];     /* entries of C those vectors hold                                        */
+    int64_t bin_bnz[4];     /* entries of B those vectors hold                                        */
+    int64_t cnz;            /* entries produced (saxpy3, dot3) */
 } gba_report;
 
 /* ------------------------------------------------------ library + memory -- */
