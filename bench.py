@@ -141,7 +141,13 @@ def main():
         torch.cuda.synchronize()
         for lo, hi in my_chunks:
             Cc = DeviceMatrix.empty(hi - lo, n, Type.FP64)
+            tw = time.perf_counter()
             rep = g.mxm(Cc, None, None, sr, view_rows(lo, hi), Bfull, None)
+            if os.environ.get("GBA_BENCH_DEBUG"):
+                tw1 = time.perf_counter()
+                Cc.free(); g.sync()
+                print(f"[bench] rows {lo}:{hi} mxm wall {1e3 * (tw1 - tw):.1f} ms kernel_ms {rep.kernel_ms:.1f} "
+                      f"free {1e3 * (time.perf_counter() - tw1):.1f} ms cnz {rep.cnz}", file=sys.stderr)
             if collect:
                 stats["phase_ms"] += np.array(rep.phase_ms[:])
                 stats["cnz"] += rep.cnz
@@ -149,6 +155,8 @@ def main():
                 stats["bin_cnz"] += np.array(rep.bin_cnz[:])
                 stats["bin_bnz"] += np.array(rep.bin_bnz[:])
                 stats["launches"] += 1
+                stats["panels"] = stats.get("panels", 0) + rep.panels
+                stats["panels_redone"] = stats.get("panels_redone", 0) + rep.panels_redone
             Cc.free()
         g.sync()
 
@@ -204,6 +212,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "avg_launch_ms": round(float(k_ms), 3), "algorithmic_bytes_per_launch": int(k_bytes)},
+            "panels_rank0": [int(stats.get("panels", 0)) // max(args.steps, 1), int(stats.get("panels_redone", 0)) // max(args.steps, 1)],
             "generate_s": round(gen_s, 1),
         }
         if not args.no_cpu_baseline:

@@ -104,7 +104,7 @@ class gba_report(C.Structure):
                 ("done_in_place", C.c_int32), ("a_transposed", C.c_int32), ("b_transposed", C.c_int32),
                 ("flops", C.c_int64), ("kernel_ms", C.c_double), ("phase_ms", C.c_double * 8),
                 ("bin_vectors", C.c_int64 * 4), ("bin_cnz", C.c_int64 * 4), ("bin_bnz", C.c_int64 * 4),
-                ("cnz", C.c_int64)]
+                ("panels", C.c_int64), ("panels_redone", C.c_int64), ("cnz", C.c_int64)]
 
 
 class GrbError(RuntimeError):
@@ -184,6 +184,8 @@ class _Lib:
             "gba_init": (i32, [C.c_int]), "gba_finalize": (i32, []),
             "gba_last_error": (C.c_char_p, []), "gba_version": (C.c_char_p, []),
             "gba_malloc": (vp, [C.c_size_t]), "gba_free": (None, [vp]),
+            "gba_pool_set_limit": (i32, [C.c_size_t]), "gba_pool_release": (i32, []),
+            "gba_pool_stats": (i32, [P(C.c_size_t), P(C.c_size_t)]),
             "gba_memcpy_h2d": (i32, [vp, vp, C.c_size_t]), "gba_memcpy_d2h": (i32, [vp, vp, C.c_size_t]),
             "gba_memset": (i32, [vp, C.c_int, C.c_size_t]), "gba_sync": (i32, []), "gba_stream": (vp, []),
             "gba_timer_start": (i32, []), "gba_timer_stop": (i32, [P(C.c_double)]),

@@ -1,6 +1,10 @@
 // Library context, device memory, prefix sums and the semiring canonicaliser.
 #include "gba_internal.hpp"
 #include <mutex>
+#include <map>
+#include <unordered_map>
+#include <iterator>
+#include <cstdlib>
 #include <cstring>
 
 namespace gba {
@@ -344,6 +348,78 @@ gba_info stage_to_device(const gba_matrix *in, gba_matrix *out, std::vector<void
     return GBA_SUCCESS;
 }
 
+// ------------------------------------------------------------ device pool --
+// hipFree of a multi-gigabyte block unmaps its pages and can stall for most of
+// a second; outputs of that size are produced and dropped on every call of a
+// graph algorithm's inner loop.  Freed blocks are therefore kept, sorted by
+// capacity, and handed out again to requests they fit with at most 2x slack
+// (the role the RMM pool plays for the reference's CUDA build,
+// rmm_wrap/rmm_wrap.h:76-83).  Blocks are reused in stream order: a block may
+// be given back while kernels that touch it are still queued on the library
+// stream, because whatever uses it next is queued behind them.
+class Pool {
+    std::mutex mu_;
+    std::multimap<size_t, void *> idle_;              // capacity -> block
+    std::unordered_map<void *, size_t> capacity_;     // every block this pool created and has not released
+    size_t cached_ = 0, live_ = 0, limit_ = (size_t)8 << 30;
+
+    static size_t round_up(size_t n) {
+        const size_t q = (n < ((size_t)1 << 20)) ? 512 : ((size_t)2 << 20);
+        return (n + q - 1) / q * q;
+    }
+    void release_locked(size_t keep) {                // largest first
+        while (cached_ > keep && !idle_.empty()) {
+            auto it = std::prev(idle_.end());
+            (void)hipFree(it->second);
+            capacity_.erase(it->second);
+            cached_ -= it->first;
+            idle_.erase(it);
+        }
+    }
+
+public:
+    void *take(size_t n) {
+        const size_t cap = round_up(n);
+        std::lock_guard<std::mutex> lock(mu_);
+        auto it = idle_.lower_bound(cap);
+        if (it != idle_.end() && it->first <= 2 * cap) {
+            void *p = it->second;
+            cached_ -= it->first; live_ += it->first;
+            idle_.erase(it);
+            return p;
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, cap) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(ctx().stream);
+            release_locked(0);
+            if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+        capacity_[p] = cap;
+        live_ += cap;
+        return p;
+    }
+    void give(void *p) {
+        std::lock_guard<std::mutex> lock(mu_);
+        auto it = capacity_.find(p);
+        if (it == capacity_.end()) { (void)hipFree(p); return; }   // not ours: a caller's own hipMalloc
+        const size_t cap = it->second;
+        live_ -= cap;
+        if (cap > limit_) { (void)hipFree(p); capacity_.erase(it); return; }
+        idle_.emplace(cap, p);
+        cached_ += cap;
+        if (cached_ > limit_) release_locked(limit_);
+    }
+    void release_all() { std::lock_guard<std::mutex> lock(mu_); release_locked(0); }
+    void set_limit(size_t n) { std::lock_guard<std::mutex> lock(mu_); limit_ = n; release_locked(limit_); }
+    void stats(size_t *cached, size_t *live) {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (cached) *cached = cached_;
+        if (live) *live = live_;
+    }
+};
+static Pool &pool() { static Pool p; return p; }
+
 }  // namespace gba
 
 // ============================================================== C ABI ======
@@ -369,6 +445,9 @@ gba_info gba_init(int device) {
     GBA_HIP(hipEventCreate(&c.ev1));
     c.device = device;
     c.inited = true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) pool().set_limit(total_b / 2);
+    if (const char *e = getenv("GBA_POOL_LIMIT_MB")) pool().set_limit((size_t)strtoull(e, nullptr, 10) << 20);
     return GBA_SUCCESS;
 }
 
@@ -376,6 +455,7 @@ gba_info gba_finalize(void) {
     Context &c = ctx();
     if (!c.inited) return GBA_SUCCESS;
     hipStreamSynchronize(c.stream);
+    pool().release_all();
     hipEventDestroy(c.ev0);
     hipEventDestroy(c.ev1);
     hipStreamDestroy(c.stream);
@@ -388,11 +468,15 @@ const char *gba_version(void) { return "graphblas_amd 0.1 (gfx950); mirrors Suit
 
 void *gba_malloc(size_t nbytes) {
     if (!ctx().inited) { set_error("gba_malloc before gba_init"); return nullptr; }
-    void *p = nullptr;
-    if (hipMalloc(&p, nbytes ? nbytes : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return p;
+    return pool().take(nbytes ? nbytes : 1);
 }
-void gba_free(void *p) { if (p) (void)hipFree(p); }
+void gba_free(void *p) { if (p) pool().give(p); }
+gba_info gba_pool_release(void) { pool().release_all(); return GBA_SUCCESS; }
+gba_info gba_pool_set_limit(size_t nbytes) { pool().set_limit(nbytes); return GBA_SUCCESS; }
+gba_info gba_pool_stats(size_t *cached_bytes, size_t *live_bytes) {
+    pool().stats(cached_bytes, live_bytes);
+    return GBA_SUCCESS;
+}
 
 gba_info gba_memcpy_h2d(void *dst, const void *src, size_t nbytes) {
     GBA_OK(require_init());

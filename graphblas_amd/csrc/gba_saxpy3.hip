@@ -303,6 +303,42 @@ __device__ inline void for_each_product(const SpView &A, const SpView &B, int64_
     }
 }
 
+// Workgroup version.  A(:,k) longer than 8*lpa entries (a hub) would leave one
+// lane group crawling while the rest of the workgroup idles, so such vectors are
+// queued in LDS and then walked by all THREADS together, coalesced.
+static constexpr int LONGQ_CAP = 2048;
+template <int THREADS, class F>
+__device__ inline void for_each_product_block(const SpView &A, const SpView &B, int64_t j, int lpa,
+                                              int *queue /* LDS [LONGQ_CAP] */, int *qn /* LDS */, F f) {
+    const int tid = threadIdx.x;
+    const int sub = tid / lpa, lane = tid - sub * lpa, nsub = THREADS / lpa;
+    const int64_t long_len = (int64_t)lpa * 8;
+    const int64_t pB0 = B.p[j], pB1 = B.p[j + 1];
+    if (tid == 0) *qn = 0;
+    __syncthreads();
+    for (int64_t pB = pB0 + sub; pB < pB1; pB += nsub) {
+        const int64_t k = B.i[pB];
+        const int64_t pA0 = A.p[k], pA1 = A.p[k + 1];
+        bool defer = false;
+        if (pA1 - pA0 > long_len) {
+            int q = 0;
+            if (lane == 0) q = atomicAdd(qn, 1);
+            q = __shfl(q, 0, lpa);
+            if (q < LONGQ_CAP) { if (lane == 0) queue[q] = (int)(pB - pB0); defer = true; }
+        }
+        if (!defer) for (int64_t pA = pA0 + lane; pA < pA1; pA += lpa) f(A.i[pA], k, pA, pB);
+    }
+    __syncthreads();
+    const int nq = (*qn < LONGQ_CAP) ? *qn : LONGQ_CAP;
+    for (int q = 0; q < nq; q++) {
+        const int64_t pB = pB0 + queue[q];
+        const int64_t k = B.i[pB];
+        const int64_t pA1 = A.p[k + 1];
+        for (int64_t pA = A.p[k] + tid; pA < pA1; pA += THREADS) f(A.i[pA], k, pA, pB);
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------- symbolic --
 // wave bin: 4 waves per workgroup, one vector per wave
 __global__ void __launch_bounds__(256)
@@ -335,12 +371,14 @@ sym_block_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
     extern __shared__ __align__(16) unsigned char smem[];
     int32_t *keys = reinterpret_cast<int32_t *>(smem);
     __shared__ int total;
+    __shared__ int longq[LONGQ_CAP];
+    __shared__ int longn;
     const int64_t j = list[blockIdx.x];
     for (int s = threadIdx.x; s < SLOTS; s += THREADS) keys[s] = HASH_EMPTY;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     int c = 0;
-    for_each_product(A, B, j, threadIdx.x, THREADS, lpa, [&](int64_t i, int64_t, int64_t, int64_t) {
+    for_each_product_block<THREADS>(A, B, j, lpa, longq, &longn, [&](int64_t i, int64_t, int64_t, int64_t) {
         if (!mask_allows(M, i, j)) return;
         bool is_new;
         hash_insert(keys, SLOTS - 1, (int32_t)i, &is_new);
@@ -384,6 +422,8 @@ sym_global_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpV
                   unsigned long long *__restrict__ next, int64_t *__restrict__ cnt) {
     __shared__ int64_t cur;
     __shared__ int scratch[16];
+    __shared__ int longq[LONGQ_CAP];
+    __shared__ int longn;
     const int64_t nf = (cvlen + 63) >> 6, ns = (nf + 63) >> 6;
     uint64_t *Hf = Hf_all + (int64_t)blockIdx.x * nf;
     uint64_t *Hs = Hs_all + (int64_t)blockIdx.x * ns;
@@ -393,7 +433,7 @@ sym_global_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpV
         const int64_t li = cur;
         if (li >= nlist) break;                 // uniform: every wave leaves here
         const int64_t j = list[li];
-        for_each_product(A, B, j, threadIdx.x, GLOBAL_THREADS, lpa, [&](int64_t i, int64_t, int64_t, int64_t) {
+        for_each_product_block<GLOBAL_THREADS>(A, B, j, lpa, longq, &longn, [&](int64_t i, int64_t, int64_t, int64_t) {
             if (!mask_allows(M, i, j)) return;
             mark_slot(Hf, Hs, i);
         });
@@ -474,13 +514,15 @@ num_block_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
     ACC *vals = reinterpret_cast<ACC *>(smem);
     int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)SLOTS * sizeof(ACC));
     __shared__ int cursor;
+    __shared__ int longq[LONGQ_CAP];
+    __shared__ int longn;
     const int64_t j = list[blockIdx.x];
     const ACC ident = (ACC)sr.identity();
     for (int s = threadIdx.x; s < SLOTS; s += THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
     if (threadIdx.x == 0) cursor = 0;
     __syncthreads();
     const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
-    for_each_product(A, B, j, threadIdx.x, THREADS, lpa, [&](int64_t i, int64_t k, int64_t pA, int64_t pB) {
+    for_each_product_block<THREADS>(A, B, j, lpa, longq, &longn, [&](int64_t i, int64_t k, int64_t pA, int64_t pB) {
         if (!mask_allows(M, i, j)) return;
         const Z t = product(sr, A, B, apat, bpat, i, k, j, pA, pB);
         bool is_new;
@@ -521,6 +563,8 @@ num_global_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView 
     using Z = typename S::z_t; using ACC = typename S::acc_t;
     __shared__ int64_t cur;
     __shared__ int wsum[GLOBAL_THREADS / 64];
+    __shared__ int longq[LONGQ_CAP];
+    __shared__ int longn;
     const int64_t nf = (cvlen + 63) >> 6, ns = (nf + 63) >> 6;
     ACC *Hx = Hx_all + (int64_t)blockIdx.x * cvlen;
     uint64_t *Hf = Hf_all + (int64_t)blockIdx.x * nf;
@@ -534,7 +578,7 @@ num_global_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView 
         const int64_t li = cur;
         if (li >= nlist) break;
         const int64_t j = list[li];
-        for_each_product(A, B, j, threadIdx.x, GLOBAL_THREADS, lpa, [&](int64_t i, int64_t k, int64_t pA, int64_t pB) {
+        for_each_product_block<GLOBAL_THREADS>(A, B, j, lpa, longq, &longn, [&](int64_t i, int64_t k, int64_t pA, int64_t pB) {
             if (!mask_allows(M, i, j)) return;
             const Z t = product(sr, A, B, apat, bpat, i, k, j, pA, pB);
             sr.atomic(&Hx[i], t);
@@ -596,6 +640,437 @@ __global__ void fill_acc_kernel(ACC *p, int64_t n, ACC v) {
     for (; idx < n; idx += stride) p[idx] = v;
 }
 
+// ------------------------------------------------------------ panel kernels --
+// Vectors too heavy for one LDS table (the CPU's Gustavson tasks and fine-task
+// teams).  HBM atomics into a dense accumulator run at the memory-side atomic
+// rate (~2e10 updates/s chip-wide), far below what the products need, so the
+// accumulator stays in LDS and the index range 0..cvlen-1 is swept in PANELS:
+// because every A(:,k) is sorted, the entries of A(:,k) that fall into the
+// current panel are one contiguous run starting at a per-neighbour cursor.
+//   symbolic: fixed panels of SYM_PANEL_WIDTH indices, one LDS bit per index
+//   numeric : LDS hash table; the panel width adapts to the density of the
+//             vector (a panel that overflows the table is redone at half width)
+// One persistent 1024-thread workgroup per CU pulls vectors from a counter.
+// Requires sorted A (not jumbled) and fewer than 2^24 entries in every B(:,j);
+// otherwise the HBM-accumulator kernels above run.
+//
+// Per neighbour t of B(:,j) the workgroup keeps, in HBM scratch, the cursor
+// into A(:,k), the index stored at the cursor, and the end of A(:,k).  A
+// neighbour with nothing inside the panel is dismissed from those coalesced
+// arrays alone, without touching A.
+static constexpr int PANEL_THREADS = 1024;
+static constexpr int PANEL_NPT = 2;                                   // neighbours searched per thread per step
+static constexpr int PANEL_STEP = PANEL_THREADS * PANEL_NPT;
+static constexpr int PANEL_SEGCAP = 4 * PANEL_THREADS;                // runs queued in LDS before they are expanded
+static constexpr int PANEL_UNROLL = 4;                                // products in flight per thread
+static constexpr int PANEL_T_BITS = 24;
+static constexpr int64_t PANEL_MAX_DEG = (int64_t)1 << PANEL_T_BITS;
+static constexpr int64_t PANEL_MAX_WIDTH = (int64_t)1 << 20;          // (SEGCAP-1) runs of this length stay below 2^32
+static constexpr int SYM_PANEL_WORDS = 24576;                         // 96 KiB of LDS
+static constexpr int64_t SYM_PANEL_WIDTH = (int64_t)SYM_PANEL_WORDS * 32;
+static constexpr int NUM_PANEL_SLOTS = 8192;
+static constexpr int NUM_PANEL_TARGET = 3000;                         // distinct indices aimed at per panel
+static constexpr int PANEL_PROBE_LIMIT = 48;
+static constexpr int64_t PANEL_INF = (int64_t)1 << 62;
+static constexpr int PANEL_SCRATCH_ARRAYS = 5;
+static_assert(SYM_PANEL_WIDTH <= PANEL_MAX_WIDTH, "symbolic panel too wide for 32-bit product offsets");
+
+// runs of the current panel waiting to be expanded (LDS)
+struct PanelSegs {
+    unsigned long long where[PANEL_SEGCAP];   // position of the run in A (high 40 bits) | neighbour ordinal (low 24)
+    uint32_t off[PANEL_SEGCAP];               // run length; exclusive prefix sum once the runs are expanded
+    uint32_t wsum[PANEL_THREADS / 64];
+    int nseg;
+    int more;                                 // some neighbour still has entries below the end of the sweep
+    int overflow;                             // the numeric table ran out of room
+    unsigned long long dbg_segs, dbg_prod, dbg_exp;
+};
+
+struct PanelCursors {
+    int64_t *cur_in, *nv_in, *cur_out, *nv_out, *end;
+    __device__ PanelCursors(int64_t *base, int64_t maxdeg)
+        : cur_in(base), nv_in(base + maxdeg), cur_out(base + 2 * maxdeg), nv_out(base + 3 * maxdeg), end(base + 4 * maxdeg) {}
+    __device__ void swap() {
+        int64_t *a = cur_in; cur_in = cur_out; cur_out = a;
+        int64_t *b = nv_in; nv_in = nv_out; nv_out = b;
+    }
+};
+
+// first p in [lo,hi) with X[p] >= target (hi if none): gallop from lo, then bisect
+__device__ inline int64_t first_ge(const int64_t *__restrict__ X, int64_t lo, int64_t hi, int64_t target) {
+    if (lo >= hi || X[lo] >= target) return lo;
+    int64_t step = 1;
+    while (lo + step < hi && X[lo + step] < target) { lo += step; step <<= 1; }
+    int64_t a = lo + 1, b = (lo + step < hi) ? lo + step : hi;
+    while (a < b) { const int64_t m = (a + b) >> 1; if (X[m] < target) a = m + 1; else b = m; }
+    return a;
+}
+
+// Expand the n queued runs: they are laid end to end (prefix sum of their
+// lengths) and the threads take the products round-robin, PANEL_UNROLL at a
+// time so that the loads of several products are in flight together; each
+// product finds its run by bisection of the prefix sums, so the work is even
+// however skewed the runs are.  load(i, pA, pB) fetches what the product
+// needs, apply(i, payload) consumes it.  Needs a barrier between the last
+// append and the call; ends on a barrier with the queue empty.
+template <class Load, class Apply>
+__device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSegs *S, Load load, Apply apply) {
+    static_assert(PANEL_SEGCAP == 4 * PANEL_THREADS, "four queue entries per thread in the scan");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b4 = tid * 4;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { v[q] = (b4 + q < n) ? S->off[b4 + q] : 0u; s += v[q]; }
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
+    if (lane == 63) S->wsum[wv] = incl;
+    __syncthreads();
+    uint32_t woff = 0, T = 0;
+#pragma unroll
+    for (int q = 0; q < PANEL_THREADS / 64; q++) { const uint32_t w = S->wsum[q]; if (q < wv) woff += w; T += w; }
+    uint32_t run = woff + incl - s;
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (b4 + q < n) { S->off[b4 + q] = run; run += v[q]; }
+    if (tid == 0) { S->nseg = 0; S->dbg_segs += (unsigned long long)n; S->dbg_prod += T; S->dbg_exp++; }
+    __syncthreads();
+    const int64_t *__restrict__ Ai = A.i;
+    for (int64_t p0 = tid; p0 < (int64_t)T; p0 += (int64_t)PANEL_UNROLL * PANEL_THREADS) {
+        uint32_t pp[PANEL_UNROLL]; bool ok[PANEL_UNROLL]; int seg[PANEL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PANEL_UNROLL; u++) {
+            const int64_t p = p0 + (int64_t)u * PANEL_THREADS;
+            ok[u] = p < (int64_t)T;
+            pp[u] = ok[u] ? (uint32_t)p : (T - 1);
+            seg[u] = 0;
+        }
+#pragma unroll
+        for (int step = PANEL_SEGCAP / 2; step > 0; step >>= 1) {
+#pragma unroll
+            for (int u = 0; u < PANEL_UNROLL; u++) {
+                const int idx = seg[u] + step;
+                if (idx < n && S->off[idx] <= pp[u]) seg[u] = idx;
+            }
+        }
+        int64_t pA[PANEL_UNROLL], pB[PANEL_UNROLL], ii[PANEL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PANEL_UNROLL; u++) {
+            const unsigned long long w = S->where[seg[u]];
+            pA[u] = (int64_t)(w >> PANEL_T_BITS) + (int64_t)(pp[u] - S->off[seg[u]]);
+            pB[u] = pB0 + (int64_t)(w & (unsigned long long)(PANEL_MAX_DEG - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < PANEL_UNROLL; u++) ii[u] = Ai[pA[u]];
+        decltype(load(ii[0], pA[0], pB[0])) payload[PANEL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PANEL_UNROLL; u++) payload[u] = load(ii[u], pA[u], pB[u]);
+#pragma unroll
+        for (int u = 0; u < PANEL_UNROLL; u++) if (ok[u]) apply(ii[u], payload[u]);
+    }
+    __syncthreads();
+}
+
+// Visit the products A(i,k)*B(k,j) with ibeg <= i < pend that have not been
+// visited yet (iend = end of the whole sweep; pend = PANEL_INF takes all that
+// is left).  PANEL_STEP neighbours at a time: each thread advances the cursors
+// of PANEL_NPT neighbours (galloping search, the loads of its neighbours issued
+// together), non-empty runs are appended to the LDS queue, and the queue is
+// expanded whenever it might not hold another step.  The caller provides a
+// barrier between resetting S->more / S->overflow and the call; the call ends
+// on a barrier.  Returns early (on a barrier) once S->overflow is raised.
+template <class Load, class Apply>
+__device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0, int64_t deg, int64_t ibeg,
+                                  int64_t pend, int64_t iend, bool first, const PanelCursors &pc, PanelSegs *S,
+                                  Load load, Apply apply) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t *__restrict__ Ai = A.i;
+    for (int64_t t0 = 0; t0 < deg; t0 += PANEL_STEP) {
+        int64_t c[PANEL_NPT], e[PANEL_NPT], nv[PANEL_NPT], stop[PANEL_NPT];
+        bool live[PANEL_NPT], need[PANEL_NPT];
+#pragma unroll
+        for (int q = 0; q < PANEL_NPT; q++) {
+            const int64_t t = t0 + (int64_t)q * PANEL_THREADS + tid;
+            live[q] = t < deg; c[q] = 0; e[q] = 0; nv[q] = PANEL_INF;
+            if (live[q]) {
+                if (first) {
+                    const int64_t k = B.i[pB0 + t];
+                    c[q] = A.p[k]; e[q] = A.p[k + 1];
+                    pc.end[t] = e[q];
+                } else {
+                    c[q] = pc.cur_in[t]; nv[q] = pc.nv_in[t];
+                }
+            }
+        }
+        if (first) {
+            if (ibeg > 0) {
+#pragma unroll
+                for (int q = 0; q < PANEL_NPT; q++) if (live[q]) c[q] = first_ge(Ai, c[q], e[q], ibeg);
+            }
+#pragma unroll
+            for (int q = 0; q < PANEL_NPT; q++) if (live[q] && c[q] < e[q]) nv[q] = Ai[c[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < PANEL_NPT; q++) {
+            need[q] = live[q] && nv[q] < pend;
+            if (need[q] && !first) e[q] = pc.end[t0 + (int64_t)q * PANEL_THREADS + tid];
+            stop[q] = c[q];
+        }
+        if (pend >= PANEL_INF) {
+#pragma unroll
+            for (int q = 0; q < PANEL_NPT; q++) if (need[q]) stop[q] = e[q];
+        } else {
+            // Ai[c] < pend is known where need: gallop to bracket the first entry >= pend, then bisect
+            int64_t lo[PANEL_NPT], st[PANEL_NPT];
+            bool g[PANEL_NPT];
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < PANEL_NPT; q++) { lo[q] = c[q]; st[q] = 1; g[q] = need[q]; any |= g[q]; }
+            while (any) {
+                int64_t pos[PANEL_NPT], xv[PANEL_NPT]; bool inb[PANEL_NPT];
+#pragma unroll
+                for (int q = 0; q < PANEL_NPT; q++) {
+                    pos[q] = lo[q] + st[q];
+                    inb[q] = g[q] && pos[q] < e[q];
+                    xv[q] = Ai[inb[q] ? pos[q] : lo[q]];
+                }
+                any = false;
+#pragma unroll
+                for (int q = 0; q < PANEL_NPT; q++) {
+                    if (inb[q] && xv[q] < pend) { lo[q] = pos[q]; st[q] <<= 1; } else g[q] = false;
+                    any |= g[q];
+                }
+            }
+            int64_t a[PANEL_NPT], b[PANEL_NPT];
+            any = false;
+#pragma unroll
+            for (int q = 0; q < PANEL_NPT; q++) {
+                a[q] = lo[q] + 1;
+                b[q] = (lo[q] + st[q] < e[q]) ? lo[q] + st[q] : e[q];
+                if (!need[q]) { a[q] = 0; b[q] = 0; }
+                any |= a[q] < b[q];
+            }
+            while (any) {
+                int64_t m[PANEL_NPT], xv[PANEL_NPT]; bool act[PANEL_NPT];
+#pragma unroll
+                for (int q = 0; q < PANEL_NPT; q++) {
+                    act[q] = a[q] < b[q];
+                    m[q] = (a[q] + b[q]) >> 1;
+                    xv[q] = Ai[act[q] ? m[q] : lo[q]];
+                }
+                any = false;
+#pragma unroll
+                for (int q = 0; q < PANEL_NPT; q++) {
+                    if (act[q]) { if (xv[q] < pend) a[q] = m[q] + 1; else b[q] = m[q]; }
+                    any |= a[q] < b[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PANEL_NPT; q++) if (need[q]) stop[q] = a[q];
+        }
+#pragma unroll
+        for (int q = 0; q < PANEL_NPT; q++) {
+            const int64_t t = t0 + (int64_t)q * PANEL_THREADS + tid;
+            if (live[q]) {
+                int64_t nv2 = nv[q];
+                if (need[q]) nv2 = (stop[q] < e[q]) ? Ai[stop[q]] : PANEL_INF;
+                pc.cur_out[t] = stop[q];
+                pc.nv_out[t] = nv2;
+                if (nv2 < iend) S->more = 1;
+            }
+            const bool has = stop[q] > c[q];
+            const unsigned long long m = __ballot(has);
+            if (m) {                                            // wave-uniform
+                int slot = 0;
+                if (lane == 0) slot = atomicAdd(&S->nseg, (int)__builtin_popcountll(m));
+                slot = __shfl(slot, 0, 64);
+                if (has) {
+                    slot += (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    S->where[slot] = ((unsigned long long)c[q] << PANEL_T_BITS) | (unsigned long long)t;
+                    S->off[slot] = (uint32_t)(stop[q] - c[q]);
+                }
+            }
+        }
+        __syncthreads();
+        const int ns = S->nseg;
+        const bool last = t0 + PANEL_STEP >= deg;
+        if (ns >= PANEL_SEGCAP - PANEL_STEP || (last && ns > 0)) {
+            panel_expand(A, pB0, ns, S, load, apply);
+            if (S->overflow) return;
+        } else {
+            __syncthreads();                                    // everyone has read nseg before the next append
+        }
+    }
+}
+
+__global__ void __launch_bounds__(PANEL_THREADS)
+sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int64_t cvlen,
+                 int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
+                 int64_t *__restrict__ cnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *bm = reinterpret_cast<uint32_t *>(smem);
+    __shared__ PanelSegs Q;
+    __shared__ int64_t row;
+    __shared__ int total;
+    for (int w = threadIdx.x; w < SYM_PANEL_WORDS; w += PANEL_THREADS) bm[w] = 0;
+    if (threadIdx.x == 0) { Q.nseg = 0; Q.overflow = 0; }
+    PanelCursors pc(scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg, maxdeg);
+    const int64_t npanels = (cvlen + SYM_PANEL_WIDTH - 1) / SYM_PANEL_WIDTH;
+    while (true) {
+        if (threadIdx.x == 0) { row = (int64_t)atomicAdd(next, 1ull); total = 0; }
+        __syncthreads();
+        const int64_t li = row;
+        if (li >= nlist) break;
+        const int64_t j = list[li];
+        const int64_t pB0 = B.p[j], deg = B.p[j + 1] - pB0;
+        int c = 0;
+        for (int64_t p = 0; p < npanels; p++) {
+            const int64_t base = p * SYM_PANEL_WIDTH;
+            const int64_t pend = (p == npanels - 1) ? PANEL_INF : base + SYM_PANEL_WIDTH;
+            if (threadIdx.x == 0) Q.more = 0;
+            __syncthreads();
+            panel_walk(A, B, pB0, deg, 0, pend, PANEL_INF, p == 0, pc, &Q,
+                [](int64_t, int64_t, int64_t) { return 0; },
+                [&](int64_t i, int) {
+                    if (!mask_allows(M, i, j)) return;
+                    const uint32_t o = (uint32_t)(i - base);
+                    atomicOr(&bm[o >> 5], 1u << (o & 31));
+                });
+            for (int w = threadIdx.x; w < SYM_PANEL_WORDS; w += PANEL_THREADS) {
+                const uint32_t x = bm[w];
+                if (x) { c += __builtin_popcount(x); bm[w] = 0; }
+            }
+            __syncthreads();
+            const int more = Q.more;
+            pc.swap();
+            __syncthreads();
+            if (!more) break;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&total, c);
+        __syncthreads();
+        if (threadIdx.x == 0) cnt[j] = total;
+        __syncthreads();
+    }
+}
+
+__device__ inline uint32_t hash_insert_limited(int32_t *keys, uint32_t mask, int32_t key) {
+    uint32_t h = (((uint32_t)key * 0x9E3779B1u) >> 19) & mask;
+    for (int probe = 0; probe < PANEL_PROBE_LIMIT; probe++) {
+        const int32_t cur = keys[h];
+        if (cur == key) return h;
+        if (cur == HASH_EMPTY) {
+            const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, key);
+            if (old == HASH_EMPTY || old == key) return h;
+        }
+        h = (h + 1) & mask;
+    }
+    return 0xffffffffu;
+}
+
+template <class S>
+__global__ void __launch_bounds__(PANEL_THREADS)
+num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int64_t cvlen,
+                 int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
+                 const int64_t *__restrict__ Cp, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx) {
+    using Z = typename S::z_t; using ACC = typename S::acc_t;
+    extern __shared__ __align__(16) unsigned char smem[];
+    ACC *vals = reinterpret_cast<ACC *>(smem);
+    int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)NUM_PANEL_SLOTS * sizeof(ACC));
+    unsigned long long st_panels = 0, st_overflows = 0;     // next[1], next[2]: panels swept / redone (reporting)
+    __shared__ PanelSegs Q;
+    __shared__ int64_t row;
+    __shared__ int out_cursor;
+    const ACC ident = (ACC)sr.identity();
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    const int lane64 = threadIdx.x & 63;
+    PanelCursors pc(scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg, maxdeg);
+    for (int s = threadIdx.x; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
+    if (threadIdx.x == 0) { Q.nseg = 0; Q.dbg_segs = Q.dbg_prod = Q.dbg_exp = 0; }
+    while (true) {
+        if (threadIdx.x == 0) row = (int64_t)atomicAdd(next, 1ull);
+        __syncthreads();
+        const int64_t li = row;
+        if (li >= nlist) break;
+        const int64_t j = list[li];
+        const int64_t pB0 = B.p[j], deg = B.p[j + 1] - pB0;
+        int64_t pC = Cp[j];
+        const int64_t cj = Cp[j + 1] - pC;
+        int64_t base = 0;
+        int64_t width = (cj > 0) ? (cvlen * NUM_PANEL_TARGET) / cj : cvlen;
+        if (width > 4096) width = 4096;                 // the low indices are the dense end of a power-law vector
+        if (width < 1) width = 1;
+        bool first = true;
+        while (true) {
+            // a panel no wider than the table needs no hashing: slot = i - base, any number of entries fits
+            const bool direct = width <= NUM_PANEL_SLOTS;
+            const int64_t lim = base + (direct ? NUM_PANEL_SLOTS : ((width < PANEL_MAX_WIDTH) ? width : PANEL_MAX_WIDTH));
+            const int64_t pend = (lim >= cvlen) ? PANEL_INF : lim;
+            if (threadIdx.x == 0) { Q.overflow = 0; Q.more = 0; out_cursor = 0; }
+            __syncthreads();
+            panel_walk(A, B, pB0, deg, 0, pend, PANEL_INF, first, pc, &Q,
+                [&](int64_t i, int64_t pA, int64_t pB) -> Z {
+                    return product(sr, A, B, apat, bpat, i, B.i[pB], j, pA, pB);
+                },
+                [&](int64_t i, Z t) {
+                    if (!mask_allows(M, i, j)) return;
+                    uint32_t h;
+                    if (direct) {
+                        h = (uint32_t)(i - base);
+                        keys[h] = (int32_t)i;
+                    } else {
+                        h = hash_insert_limited(keys, NUM_PANEL_SLOTS - 1, (int32_t)i);
+                        if (h == 0xffffffffu) { Q.overflow = 1; return; }
+                    }
+                    sr.atomic(&vals[h], t);
+                });
+            if (Q.overflow) {                            // uniform: raised before the barrier that ended the walk
+                width = (width > 1) ? (width >> 1) : 1;
+                st_overflows++;
+                for (int s = threadIdx.x; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
+                __syncthreads();
+                continue;
+            }
+            // emit the panel (wave-aggregated positions, coalesced stores) and leave the table clean
+            for (int s = threadIdx.x; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) {
+                const int32_t key = keys[s];
+                const bool occ = (key != HASH_EMPTY);
+                const unsigned long long m = __ballot(occ);
+                int wbase = 0;
+                if (lane64 == 0 && m) wbase = atomicAdd(&out_cursor, __builtin_popcountll(m));
+                wbase = __shfl(wbase, 0, 64);
+                if (occ) {
+                    const int64_t q = pC + wbase + __builtin_popcountll(m & ((1ull << lane64) - 1));
+                    Ci[q] = key;
+                    Cx[q] = (Z)vals[s];
+                    keys[s] = HASH_EMPTY;
+                    vals[s] = ident;
+                }
+            }
+            __syncthreads();
+            const int d = out_cursor;
+            const int more = Q.more;
+            pC += d;
+            pc.swap();
+            first = false;
+            base = lim;
+            st_panels++;
+            if (d == 0) width = (width < cvlen) ? (width << 2) : width;
+            else {
+                const int64_t covered = direct ? (int64_t)NUM_PANEL_SLOTS : width;
+                int64_t w2 = (int64_t)((double)covered * (double)NUM_PANEL_TARGET / (double)d);
+                if (w2 > 4 * covered) w2 = 4 * covered;
+                if (w2 < 1) w2 = 1;
+                width = w2;
+            }
+            __syncthreads();
+            if (!more) break;
+        }
+    }
+    if (threadIdx.x == 0) { atomicAdd(&next[1], st_panels); atomicAdd(&next[2], st_overflows);
+        atomicAdd(&next[3], Q.dbg_segs); atomicAdd(&next[4], Q.dbg_prod); atomicAdd(&next[5], Q.dbg_exp); }
+}
+
 // ------------------------------------------------------------------ driver --
 static int pick_lpa(const gba_matrix *A) {
     // threads that share one A(:,k): about its average length, a power of two in [4,64]
@@ -649,6 +1124,10 @@ struct Saxpy3Plan {
     int64_t *Cp, *Ci; void *Cx;
     PhaseClock *clock = nullptr;
     int ev_num[5] = {-1, -1, -1, -1, -1};   // before wave, blk1, blk2, global, after global
+    bool A_sorted = false;                  // vectors of A in index order: panel kernels usable
+    int64_t maxdeg = 0;                     // longest vector of B
+    const int64_t *vflops = nullptr;        // per-vector flop count (device)
+    unsigned long long panel_stats[6] = {0, 0, 0, 0, 0, 0};   // rows pulled, panels swept, panels redone
 };
 
 template <class S>
@@ -681,11 +1160,31 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
     }
     GBA_HIP(hipGetLastError());
     mark(3);
-    if (nb.count[BIN_GLOBAL] > 0) {
+    if (nb.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) {
+        int64_t nblocks = (int64_t)ctx().num_cu;
+        if (nblocks > nb.count[BIN_GLOBAL]) nblocks = nb.count[BIN_GLOBAL];
+        DevBuf scratch, next;
+        GBA_OK(scratch.alloc((size_t)nblocks * PANEL_SCRATCH_ARRAYS * (size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
+        GBA_OK(next.alloc(64));
+        GBA_HIP(hipMemsetAsync(next.p, 0, 64, st));
+        auto k = num_panel_kernel<S>;
+        const size_t lds = (size_t)NUM_PANEL_SLOTS * (sizeof(ACC) + 4);
+        GBA_OK(set_lds(k, lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
+                           sr, nb.count[BIN_GLOBAL], nb.list(BIN_GLOBAL), P.A, P.B, P.M, P.cvlen, P.maxdeg,
+                           scratch.as<int64_t>(), next.as<unsigned long long>(), P.Cp, P.Ci, Cx);
+        GBA_HIP(hipGetLastError());
+        mark(4);
+        GBA_HIP(hipMemcpyAsync(P.panel_stats, next.p, 48, hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipStreamSynchronize(st));      // scratch is released on return
+    } else if (nb.count[BIN_GLOBAL] > 0) {
         const int64_t nf = (P.cvlen + 63) >> 6, ns = (nf + 63) >> 6;
         const size_t per_block = (size_t)P.cvlen * sizeof(ACC) + (size_t)(nf + ns) * 8;
         size_t free_b = 0, total_b = 0;
         GBA_HIP(hipMemGetInfo(&free_b, &total_b));
+        size_t idle_b = 0;
+        gba_pool_stats(&idle_b, nullptr);               // idle pool blocks are released on demand
+        free_b += idle_b;
         int64_t nblocks = 2 * (int64_t)ctx().num_cu;
         if (nblocks > nb.count[BIN_GLOBAL]) nblocks = nb.count[BIN_GLOBAL];
         const int64_t fit = (int64_t)((free_b / 2) / per_block);
@@ -737,7 +1236,21 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
                            sb.count[BIN_BLK2], sb.list(BIN_BLK2), P.A, P.B, P.M, P.lpa, cnt);
     }
     GBA_HIP(hipGetLastError());
-    if (sb.count[BIN_GLOBAL] > 0) {
+    if (sb.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) {
+        int64_t nblocks = (int64_t)ctx().num_cu;
+        if (nblocks > sb.count[BIN_GLOBAL]) nblocks = sb.count[BIN_GLOBAL];
+        DevBuf scratch, next;
+        GBA_OK(scratch.alloc((size_t)nblocks * PANEL_SCRATCH_ARRAYS * (size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
+        GBA_OK(next.alloc(8));
+        GBA_HIP(hipMemsetAsync(next.p, 0, 8, st));
+        const size_t lds = (size_t)SYM_PANEL_WORDS * 4;
+        GBA_OK(set_lds(sym_panel_kernel, lds));
+        hipLaunchKernelGGL(sym_panel_kernel, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
+                           sb.count[BIN_GLOBAL], sb.list(BIN_GLOBAL), P.A, P.B, P.M, P.cvlen, P.maxdeg,
+                           scratch.as<int64_t>(), next.as<unsigned long long>(), cnt);
+        GBA_HIP(hipGetLastError());
+        GBA_HIP(hipStreamSynchronize(st));
+    } else if (sb.count[BIN_GLOBAL] > 0) {
         const int64_t nf = (P.cvlen + 63) >> 6, ns = (nf + 63) >> 6;
         int64_t nblocks = 2 * (int64_t)ctx().num_cu;
         if (nblocks > sb.count[BIN_GLOBAL]) nblocks = sb.count[BIN_GLOBAL];
@@ -787,6 +1300,9 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     DevBuf vflops; GBA_OK(vflops.alloc((size_t)(nvec + 1) * 8));
     GBA_OK(saxpy3_flopcount(nullptr, vflops.as<int64_t>(), nullptr, false, A, B));
     GBA_OK(build_bins(nvec, vflops.as<int64_t>(), false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, SYM_BLK2_MAX}, &P.sym));
+    P.A_sorted = !A->jumbled;
+    P.vflops = vflops.as<int64_t>();
+    if (P.sym.count[BIN_GLOBAL] > 0) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
     const int e1 = clock.mark();
 
     // phase 1: symbolic, cnt[j] = nnz C(:,j), written into the future C->p
@@ -797,6 +1313,7 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
 
     // numeric bins use the exact counts, taken before the prefix sum
     GBA_OK(build_bins(nvec, Cp.as<int64_t>(), false, BinLimits{NUM_WAVE_MAX, NUM_BLK1_MAX, NUM_BLK2_MAX}, &P.num));
+    if (P.num.count[BIN_GLOBAL] > 0 && P.maxdeg == 0) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
 
     // phases 3/4: Cp = cumsum (cnt)
     GBA_OK(dev_cumsum_i64(Cp.as<int64_t>(), nvec, st));
@@ -828,6 +1345,10 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         rep->cnz = cnz;
         rep->bin_vectors[0] = P.num.count[BIN_WAVE]; rep->bin_vectors[1] = P.num.count[BIN_BLK1];
         rep->bin_vectors[2] = P.num.count[BIN_BLK2]; rep->bin_vectors[3] = P.num.count[BIN_GLOBAL];
+        rep->panels = (int64_t)P.panel_stats[1]; rep->panels_redone = (int64_t)P.panel_stats[2];
+        if (getenv("GBA_PANEL_PROF"))
+            fprintf(stderr, "[gba] panels %llu redone %llu segs %llu products %llu expands %llu\n",
+                    P.panel_stats[1], P.panel_stats[2], P.panel_stats[3], P.panel_stats[4], P.panel_stats[5]);
         DevBuf bs; GBA_OK(bs.alloc(8 * 8));
         GBA_HIP(hipMemsetAsync(bs.p, 0, 64, st));
         for (int b = 0; b < 4; b++) {

@@ -173,6 +173,8 @@ typedef struct gba_report {
     int64_t bin_vectors[4]; /* saxpy3 numeric: vectors routed to wave / block1 / block2 / global bins */
     int64_t bin_cnz[4];     /* entries of C those vectors hold                                        */
     int64_t bin_bnz[4];     /* entries of B those vectors hold                                        */
+    int64_t panels;         /* saxpy3 numeric, heavy vectors: LDS panels swept, and panels redone at   */
+    int64_t panels_redone;  /* half width after a table overflow                                      */
     int64_t cnz;            /* entries produced (saxpy3, dot3) */
 } gba_report;
 
@@ -189,6 +191,14 @@ const char *gba_version(void);
  * given in GPU mode (Source/GB_init.c:84-95). */
 void    *gba_malloc(size_t nbytes);
 void     gba_free(void *p);
+/* gba_free keeps blocks for reuse by later gba_malloc calls (hipFree of a
+ * multi-gigabyte block stalls for hundreds of ms); the reference's CUDA build
+ * gets the same from its RMM pool (rmm_wrap/rmm_wrap.h:53-83).  The pool holds
+ * at most `limit` idle bytes (default: half of the device memory, or
+ * GBA_POOL_LIMIT_MB), and is emptied before an allocation is reported failed. */
+gba_info gba_pool_set_limit(size_t nbytes);
+gba_info gba_pool_release(void);           /* hipFree every idle block now */
+gba_info gba_pool_stats(size_t *idle_bytes, size_t *live_bytes);
 gba_info gba_memcpy_h2d(void *dst, const void *src, size_t nbytes);
 gba_info gba_memcpy_d2h(void *dst, const void *src, size_t nbytes);
 gba_info gba_memset(void *dst, int byte, size_t nbytes);
