@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgraphblas_amd.so")
+LIB_PATH = os.environ.get("GBA_LIB_PATH") or os.path.join(_HERE, "libgraphblas_amd.so")   # override: kernel A/B runs
 
 
 class Info:

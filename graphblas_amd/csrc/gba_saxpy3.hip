@@ -669,11 +669,15 @@ static constexpr int64_t PANEL_MAX_WIDTH = (int64_t)1 << 20;          // (SEGCAP
 static constexpr int SYM_PANEL_WORDS = 24576;                         // 96 KiB of LDS
 static constexpr int64_t SYM_PANEL_WIDTH = (int64_t)SYM_PANEL_WORDS * 32;
 static constexpr int NUM_PANEL_SLOTS = 8192;
-static constexpr int NUM_PANEL_TARGET = 3000;                         // distinct indices aimed at per panel
+static constexpr int NUM_PANEL_TARGET = 3000;                         // distinct indices aimed at per panel (no boundaries known)
+static constexpr int NUM_PANEL_FIT = 4096;                            // entries between two recorded boundaries
+static constexpr int SYM_WORDS_PER_THREAD = SYM_PANEL_WORDS / PANEL_THREADS;
 static constexpr int PANEL_PROBE_LIMIT = 48;
 static constexpr int64_t PANEL_INF = (int64_t)1 << 62;
 static constexpr int PANEL_SCRATCH_ARRAYS = 5;
 static_assert(SYM_PANEL_WIDTH <= PANEL_MAX_WIDTH, "symbolic panel too wide for 32-bit product offsets");
+static_assert(SYM_WORDS_PER_THREAD * PANEL_THREADS == SYM_PANEL_WORDS && SYM_WORDS_PER_THREAD * 32 < NUM_PANEL_FIT,
+              "each thread owns a bitmap slice that can hold at most one boundary");
 
 // runs of the current panel waiting to be expanded (LDS)
 struct PanelSegs {
@@ -683,7 +687,6 @@ struct PanelSegs {
     int nseg;
     int more;                                 // some neighbour still has entries below the end of the sweep
     int overflow;                             // the numeric table ran out of room
-    unsigned long long dbg_segs, dbg_prod, dbg_exp;
 };
 
 struct PanelCursors {
@@ -710,8 +713,8 @@ __device__ inline int64_t first_ge(const int64_t *__restrict__ X, int64_t lo, in
 // lengths) and the threads take the products round-robin, PANEL_UNROLL at a
 // time so that the loads of several products are in flight together; each
 // product finds its run by bisection of the prefix sums, so the work is even
-// however skewed the runs are.  load(i, pA, pB) fetches what the product
-// needs, apply(i, payload) consumes it.  Needs a barrier between the last
+// however skewed the runs are.  load(i, pA, pB) fetches what one product
+// needs; apply(i[], payload[], ok[]) consumes a batch of PANEL_UNROLL.  Needs a barrier between the last
 // append and the call; ends on a barrier with the queue empty.
 template <class Load, class Apply>
 __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSegs *S, Load load, Apply apply) {
@@ -732,9 +735,11 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
     uint32_t run = woff + incl - s;
 #pragma unroll
     for (int q = 0; q < 4; q++) if (b4 + q < n) { S->off[b4 + q] = run; run += v[q]; }
-    if (tid == 0) { S->nseg = 0; S->dbg_segs += (unsigned long long)n; S->dbg_prod += T; S->dbg_exp++; }
+    if (tid == 0) S->nseg = 0;
     __syncthreads();
     const int64_t *__restrict__ Ai = A.i;
+    int top = 1;                                        // largest power of two below n (bisection stride)
+    while (top * 2 < n) top <<= 1;
     for (int64_t p0 = tid; p0 < (int64_t)T; p0 += (int64_t)PANEL_UNROLL * PANEL_THREADS) {
         uint32_t pp[PANEL_UNROLL]; bool ok[PANEL_UNROLL]; int seg[PANEL_UNROLL];
 #pragma unroll
@@ -744,8 +749,7 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
             pp[u] = ok[u] ? (uint32_t)p : (T - 1);
             seg[u] = 0;
         }
-#pragma unroll
-        for (int step = PANEL_SEGCAP / 2; step > 0; step >>= 1) {
+        for (int step = top; step > 0; step >>= 1) {
 #pragma unroll
             for (int u = 0; u < PANEL_UNROLL; u++) {
                 const int idx = seg[u] + step;
@@ -764,8 +768,7 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
         decltype(load(ii[0], pA[0], pB[0])) payload[PANEL_UNROLL];
 #pragma unroll
         for (int u = 0; u < PANEL_UNROLL; u++) payload[u] = load(ii[u], pA[u], pB[u]);
-#pragma unroll
-        for (int u = 0; u < PANEL_UNROLL; u++) if (ok[u]) apply(ii[u], payload[u]);
+        apply(ii, payload, ok);
     }
     __syncthreads();
 }
@@ -902,77 +905,118 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
     }
 }
 
+// room[j] = boundaries vector j can have at most (0 for vectors the panel kernel does not count)
+__global__ void __launch_bounds__(256)
+bounds_room_kernel(int64_t nvec, const int64_t *__restrict__ vflops, int64_t cvlen, int64_t panel_min_flops,
+                   int64_t *__restrict__ room) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx <= nvec; idx += stride) {
+        int64_t r = 0;
+        if (idx < nvec && vflops[idx] > panel_min_flops) {
+            const int64_t most = (vflops[idx] < cvlen) ? vflops[idx] : cvlen;
+            r = most / NUM_PANEL_FIT + 1;
+        }
+        room[idx] = r;
+    }
+}
+
+// The symbolic sweep also records, for the numeric sweep, where the vector's
+// pattern crosses every multiple of NUM_PANEL_FIT entries: bounds[bstart[j] + m - 1]
+// is one past the index of the (m * NUM_PANEL_FIT)-th entry of C(:,j).  Panels cut
+// at those indices fill the numeric table to exactly one half.
 __global__ void __launch_bounds__(PANEL_THREADS)
 sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int64_t cvlen,
                  int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
-                 int64_t *__restrict__ cnt) {
+                 int64_t *__restrict__ cnt, const int64_t *__restrict__ bstart, int64_t *__restrict__ bounds) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *bm = reinterpret_cast<uint32_t *>(smem);
     __shared__ PanelSegs Q;
     __shared__ int64_t row;
-    __shared__ int total;
-    for (int w = threadIdx.x; w < SYM_PANEL_WORDS; w += PANEL_THREADS) bm[w] = 0;
-    if (threadIdx.x == 0) { Q.nseg = 0; Q.overflow = 0; }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int w = tid; w < SYM_PANEL_WORDS; w += PANEL_THREADS) bm[w] = 0;
+    if (tid == 0) { Q.nseg = 0; Q.overflow = 0; }
     PanelCursors pc(scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg, maxdeg);
     const int64_t npanels = (cvlen + SYM_PANEL_WIDTH - 1) / SYM_PANEL_WIDTH;
     while (true) {
-        if (threadIdx.x == 0) { row = (int64_t)atomicAdd(next, 1ull); total = 0; }
+        if (tid == 0) row = (int64_t)atomicAdd(next, 1ull);
         __syncthreads();
         const int64_t li = row;
         if (li >= nlist) break;
         const int64_t j = list[li];
         const int64_t pB0 = B.p[j], deg = B.p[j + 1] - pB0;
-        int c = 0;
+        int64_t *jb = bounds + bstart[j];
+        int64_t seen = 0;                                   // entries of C(:,j) below the current panel
         for (int64_t p = 0; p < npanels; p++) {
             const int64_t base = p * SYM_PANEL_WIDTH;
             const int64_t pend = (p == npanels - 1) ? PANEL_INF : base + SYM_PANEL_WIDTH;
-            if (threadIdx.x == 0) Q.more = 0;
+            if (tid == 0) Q.more = 0;
             __syncthreads();
             panel_walk(A, B, pB0, deg, 0, pend, PANEL_INF, p == 0, pc, &Q,
                 [](int64_t, int64_t, int64_t) { return 0; },
-                [&](int64_t i, int) {
-                    if (!mask_allows(M, i, j)) return;
-                    const uint32_t o = (uint32_t)(i - base);
-                    atomicOr(&bm[o >> 5], 1u << (o & 31));
+                [&](const int64_t (&i)[PANEL_UNROLL], const int (&)[PANEL_UNROLL], const bool (&ok)[PANEL_UNROLL]) {
+#pragma unroll
+                    for (int u = 0; u < PANEL_UNROLL; u++) {
+                        if (!ok[u] || !mask_allows(M, i[u], j)) continue;
+                        const uint32_t o = (uint32_t)(i[u] - base);
+                        atomicOr(&bm[o >> 5], 1u << (o & 31));
+                    }
                 });
-            for (int w = threadIdx.x; w < SYM_PANEL_WORDS; w += PANEL_THREADS) {
-                const uint32_t x = bm[w];
-                if (x) { c += __builtin_popcount(x); bm[w] = 0; }
+            // count in index order: each thread owns SYM_WORDS_PER_THREAD consecutive words
+            uint32_t x[SYM_WORDS_PER_THREAD];
+            int mine = 0;
+            const int w0 = tid * SYM_WORDS_PER_THREAD;
+#pragma unroll
+            for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) {
+                x[q] = bm[w0 + q];
+                if (x[q]) { mine += __builtin_popcount(x[q]); bm[w0 + q] = 0; }
             }
+            int incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
+            if (lane == 63) Q.wsum[wv] = (uint32_t)incl;
             __syncthreads();
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < PANEL_THREADS / 64; q++) { const int w = (int)Q.wsum[q]; if (q < wv) woff += w; total += w; }
+            const int64_t lo = seen + woff + incl - mine;   // entries before this thread's slice
+            const int64_t m = lo / NUM_PANEL_FIT + 1;       // the next multiple to be crossed
+            if (m * NUM_PANEL_FIT <= lo + mine) {
+                int r = (int)(m * NUM_PANEL_FIT - lo);      // the r-th set bit of the slice, 1-based
+#pragma unroll
+                for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) {
+                    const int pcq = __builtin_popcount(x[q]);
+                    if (r > 0 && r <= pcq) {
+                        uint32_t y = x[q];
+                        for (int z = 1; z < r; z++) y &= y - 1;
+                        jb[m - 1] = base + (int64_t)(w0 + q) * 32 + __builtin_ctz(y) + 1;
+                        r = 0;
+                    } else if (r > 0) {
+                        r -= pcq;
+                    }
+                }
+            }
+            seen += total;
             const int more = Q.more;
             pc.swap();
             __syncthreads();
             if (!more) break;
         }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&total, c);
-        __syncthreads();
-        if (threadIdx.x == 0) cnt[j] = total;
-        __syncthreads();
+        if (tid == 0) cnt[j] = seen;
     }
 }
 
-__device__ inline uint32_t hash_insert_limited(int32_t *keys, uint32_t mask, int32_t key) {
-    uint32_t h = (((uint32_t)key * 0x9E3779B1u) >> 19) & mask;
-    for (int probe = 0; probe < PANEL_PROBE_LIMIT; probe++) {
-        const int32_t cur = keys[h];
-        if (cur == key) return h;
-        if (cur == HASH_EMPTY) {
-            const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, key);
-            if (old == HASH_EMPTY || old == key) return h;
-        }
-        h = (h + 1) & mask;
-    }
-    return 0xffffffffu;
-}
+// Multiplicative (Fibonacci) hash into NUM_PANEL_SLOTS = 2^13 slots.  The order in which a panel's
+// entries leave the table is free (C is returned jumbled), so the function need not be GB_HASHF.
+__device__ inline uint32_t panel_hash(int32_t key) { return ((uint32_t)key * 0x9E3779B1u) >> 19; }
+static_assert(NUM_PANEL_SLOTS == (1 << 13), "panel_hash keeps the top 13 bits");
 
 template <class S>
 __global__ void __launch_bounds__(PANEL_THREADS)
 num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int64_t cvlen,
                  int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
-                 const int64_t *__restrict__ Cp, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx) {
+                 const int64_t *__restrict__ Cp, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx,
+                 const int64_t *__restrict__ bstart, const int64_t *__restrict__ bounds) {
     using Z = typename S::z_t; using ACC = typename S::acc_t;
     extern __shared__ __align__(16) unsigned char smem[];
     ACC *vals = reinterpret_cast<ACC *>(smem);
@@ -986,7 +1030,7 @@ num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
     const int lane64 = threadIdx.x & 63;
     PanelCursors pc(scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg, maxdeg);
     for (int s = threadIdx.x; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
-    if (threadIdx.x == 0) { Q.nseg = 0; Q.dbg_segs = Q.dbg_prod = Q.dbg_exp = 0; }
+    if (threadIdx.x == 0) Q.nseg = 0;
     while (true) {
         if (threadIdx.x == 0) row = (int64_t)atomicAdd(next, 1ull);
         __syncthreads();
@@ -1001,7 +1045,18 @@ num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
         if (width > 4096) width = 4096;                 // the low indices are the dense end of a power-law vector
         if (width < 1) width = 1;
         bool first = true;
+        // boundaries recorded by the symbolic sweep, if it was the panel kernel that counted this vector
+        const int64_t *jb = nullptr;
+        int64_t nb = 0, mb = 0;
+        if (bstart && bstart[j + 1] > bstart[j]) { jb = bounds + bstart[j]; nb = cj / NUM_PANEL_FIT; }
+        int64_t shrink = 0;                             // halvings after an overflow (never needed with boundaries)
         while (true) {
+            if (jb) {
+                while (mb < nb && jb[mb] <= base) mb++;
+                width = ((mb < nb) ? jb[mb] : cvlen) - base;
+                width >>= shrink;
+                if (width < 1) width = 1;
+            }
             // a panel no wider than the table needs no hashing: slot = i - base, any number of entries fits
             const bool direct = width <= NUM_PANEL_SLOTS;
             const int64_t lim = base + (direct ? NUM_PANEL_SLOTS : ((width < PANEL_MAX_WIDTH) ? width : PANEL_MAX_WIDTH));
@@ -1012,20 +1067,40 @@ num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
                 [&](int64_t i, int64_t pA, int64_t pB) -> Z {
                     return product(sr, A, B, apat, bpat, i, B.i[pB], j, pA, pB);
                 },
-                [&](int64_t i, Z t) {
-                    if (!mask_allows(M, i, j)) return;
-                    uint32_t h;
+                [&](const int64_t (&i)[PANEL_UNROLL], const Z (&t)[PANEL_UNROLL], const bool (&ok)[PANEL_UNROLL]) {
+                    bool todo[PANEL_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < PANEL_UNROLL; u++) todo[u] = ok[u] && mask_allows(M, i[u], j);
                     if (direct) {
-                        h = (uint32_t)(i - base);
-                        keys[h] = (int32_t)i;
-                    } else {
-                        h = hash_insert_limited(keys, NUM_PANEL_SLOTS - 1, (int32_t)i);
-                        if (h == 0xffffffffu) { Q.overflow = 1; return; }
+#pragma unroll
+                        for (int u = 0; u < PANEL_UNROLL; u++) if (todo[u]) {
+                            const uint32_t h = (uint32_t)(i[u] - base);
+                            keys[h] = (int32_t)i[u];
+                            sr.atomic(&vals[h], t[u]);
+                        }
+                        return;
                     }
-                    sr.atomic(&vals[h], t);
+                    // open addressing, linear probing
+#pragma unroll
+                    for (int u = 0; u < PANEL_UNROLL; u++) if (todo[u]) {
+                        const int32_t key = (int32_t)i[u];
+                        uint32_t h = panel_hash(key);
+                        bool placed = false;
+                        for (int probe = 0; probe < PANEL_PROBE_LIMIT; probe++) {
+                            const int32_t cur = keys[h];
+                            if (cur == key) { placed = true; break; }
+                            if (cur == HASH_EMPTY) {
+                                const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, key);
+                                if (old == HASH_EMPTY || old == key) { placed = true; break; }
+                            }
+                            h = (h + 1) & (NUM_PANEL_SLOTS - 1);
+                        }
+                        if (placed) sr.atomic(&vals[h], t[u]); else Q.overflow = 1;
+                    }
                 });
             if (Q.overflow) {                            // uniform: raised before the barrier that ended the walk
                 width = (width > 1) ? (width >> 1) : 1;
+                shrink++;
                 st_overflows++;
                 for (int s = threadIdx.x; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
                 __syncthreads();
@@ -1054,6 +1129,7 @@ num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
             pc.swap();
             first = false;
             base = lim;
+            shrink = 0;
             st_panels++;
             if (d == 0) width = (width < cvlen) ? (width << 2) : width;
             else {
@@ -1067,8 +1143,7 @@ num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
             if (!more) break;
         }
     }
-    if (threadIdx.x == 0) { atomicAdd(&next[1], st_panels); atomicAdd(&next[2], st_overflows);
-        atomicAdd(&next[3], Q.dbg_segs); atomicAdd(&next[4], Q.dbg_prod); atomicAdd(&next[5], Q.dbg_exp); }
+    if (threadIdx.x == 0) { atomicAdd(&next[1], st_panels); atomicAdd(&next[2], st_overflows); }
 }
 
 // ------------------------------------------------------------------ driver --
@@ -1127,7 +1202,9 @@ struct Saxpy3Plan {
     bool A_sorted = false;                  // vectors of A in index order: panel kernels usable
     int64_t maxdeg = 0;                     // longest vector of B
     const int64_t *vflops = nullptr;        // per-vector flop count (device)
-    unsigned long long panel_stats[6] = {0, 0, 0, 0, 0, 0};   // rows pulled, panels swept, panels redone
+    const int64_t *bstart = nullptr;        // panel boundaries of vector j: bounds[bstart[j] .. bstart[j+1])
+    int64_t *bounds = nullptr;
+    unsigned long long panel_stats[3] = {0, 0, 0};   // rows pulled, panels swept, panels redone
 };
 
 template <class S>
@@ -1165,17 +1242,17 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         if (nblocks > nb.count[BIN_GLOBAL]) nblocks = nb.count[BIN_GLOBAL];
         DevBuf scratch, next;
         GBA_OK(scratch.alloc((size_t)nblocks * PANEL_SCRATCH_ARRAYS * (size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
-        GBA_OK(next.alloc(64));
-        GBA_HIP(hipMemsetAsync(next.p, 0, 64, st));
+        GBA_OK(next.alloc(24));
+        GBA_HIP(hipMemsetAsync(next.p, 0, 24, st));
         auto k = num_panel_kernel<S>;
         const size_t lds = (size_t)NUM_PANEL_SLOTS * (sizeof(ACC) + 4);
         GBA_OK(set_lds(k, lds));
         hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
                            sr, nb.count[BIN_GLOBAL], nb.list(BIN_GLOBAL), P.A, P.B, P.M, P.cvlen, P.maxdeg,
-                           scratch.as<int64_t>(), next.as<unsigned long long>(), P.Cp, P.Ci, Cx);
+                           scratch.as<int64_t>(), next.as<unsigned long long>(), P.Cp, P.Ci, Cx, P.bstart, P.bounds);
         GBA_HIP(hipGetLastError());
         mark(4);
-        GBA_HIP(hipMemcpyAsync(P.panel_stats, next.p, 48, hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipMemcpyAsync(P.panel_stats, next.p, 24, hipMemcpyDeviceToHost, st));
         GBA_HIP(hipStreamSynchronize(st));      // scratch is released on return
     } else if (nb.count[BIN_GLOBAL] > 0) {
         const int64_t nf = (P.cvlen + 63) >> 6, ns = (nf + 63) >> 6;
@@ -1247,7 +1324,7 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
         GBA_OK(set_lds(sym_panel_kernel, lds));
         hipLaunchKernelGGL(sym_panel_kernel, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
                            sb.count[BIN_GLOBAL], sb.list(BIN_GLOBAL), P.A, P.B, P.M, P.cvlen, P.maxdeg,
-                           scratch.as<int64_t>(), next.as<unsigned long long>(), cnt);
+                           scratch.as<int64_t>(), next.as<unsigned long long>(), cnt, P.bstart, P.bounds);
         GBA_HIP(hipGetLastError());
         GBA_HIP(hipStreamSynchronize(st));
     } else if (sb.count[BIN_GLOBAL] > 0) {
@@ -1303,6 +1380,20 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     P.A_sorted = !A->jumbled;
     P.vflops = vflops.as<int64_t>();
     if (P.sym.count[BIN_GLOBAL] > 0) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
+    DevBuf bstart, bounds;
+    if (P.sym.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) {
+        GBA_OK(bstart.alloc((size_t)(nvec + 1) * 8));
+        int64_t blocks = ceil_div(nvec + 1, 256); if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(bounds_room_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, vflops.as<int64_t>(),
+                           P.cvlen, (int64_t)SYM_BLK2_MAX, bstart.as<int64_t>());
+        GBA_HIP(hipGetLastError());
+        GBA_OK(dev_cumsum_i64(bstart.as<int64_t>(), nvec, st));
+        int64_t room = 0;
+        GBA_OK(dev_read_i64(bstart.as<int64_t>() + nvec, &room));
+        GBA_OK(bounds.alloc((size_t)(room > 0 ? room : 1) * 8));
+        P.bstart = bstart.as<int64_t>();
+        P.bounds = bounds.as<int64_t>();
+    }
     const int e1 = clock.mark();
 
     // phase 1: symbolic, cnt[j] = nnz C(:,j), written into the future C->p
@@ -1346,9 +1437,6 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         rep->bin_vectors[0] = P.num.count[BIN_WAVE]; rep->bin_vectors[1] = P.num.count[BIN_BLK1];
         rep->bin_vectors[2] = P.num.count[BIN_BLK2]; rep->bin_vectors[3] = P.num.count[BIN_GLOBAL];
         rep->panels = (int64_t)P.panel_stats[1]; rep->panels_redone = (int64_t)P.panel_stats[2];
-        if (getenv("GBA_PANEL_PROF"))
-            fprintf(stderr, "[gba] panels %llu redone %llu segs %llu products %llu expands %llu\n",
-                    P.panel_stats[1], P.panel_stats[2], P.panel_stats[3], P.panel_stats[4], P.panel_stats[5]);
         DevBuf bs; GBA_OK(bs.alloc(8 * 8));
         GBA_HIP(hipMemsetAsync(bs.p, 0, 64, st));
         for (int b = 0; b < 4; b++) {

@@ -1,0 +1,165 @@
+"""GPU parity for the heavy-vector path of gba_AxB_saxpy3: output vectors with more entries than
+one LDS table holds are swept in index panels (symbolic: bitmap panels that also record the
+numeric panel boundaries; numeric: hashed or directly addressed panels).  Every case is compared
+with the CPU oracle through the C ABI; values are small integers so that sums are exact."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from graphblas_amd import Matrix, Type, gen
+from oracle import oracle
+from util import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def _heavy_pair(n, ncols, deg, nhubs, hub_len, light_len, seed, dense_cols=0):
+    """A (n x n) with `nhubs` long columns and short ones elsewhere; B (n x ncols) whose columns
+    each name `deg` columns of A, hubs included: every C(:,j) is a heavy vector."""
+    rng = np.random.default_rng(seed)
+    hubs = rng.choice(n, nhubs, replace=False)
+    rows = [rng.integers(0, n, n * light_len)]
+    cols = [np.repeat(np.arange(n), light_len)]
+    for h in hubs:
+        rows.append(rng.choice(n, hub_len, replace=False)); cols.append(np.full(hub_len, h))
+    for d in rng.choice(n, dense_cols, replace=False) if dense_cols else []:
+        rows.append(np.arange(n)); cols.append(np.full(n, d))     # completely dense columns of A
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    A = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n)).tocsc()
+    A.sum_duplicates(); A.data[:] = rng.integers(1, 4, len(A.data))
+    bc, br = [], []
+    for j in range(ncols):
+        k = np.unique(np.concatenate([hubs[: max(1, nhubs - j)], rng.integers(0, n, deg)]))
+        br.append(k); bc.append(np.full(len(k), j))
+    br, bc = np.concatenate(br), np.concatenate(bc)
+    B = sp.coo_matrix((rng.integers(1, 4, len(br)).astype(np.float64), (br, bc)), shape=(n, ncols)).tocsc()
+    return A, B
+
+
+def _run(gba, A, B, sr, M=None, comp=False, struct=True):
+    dA, dB = A.to_device(), B.to_device()
+    dM = M.to_device() if M is not None else None
+    out, rep, _ = gba.AxB_saxpy3(dM, comp, struct, dA, dB, sr)
+    got = out.to_host()
+    for d in (dA, dB, dM, out):
+        if d is not None:
+            d.free()
+    return got, rep
+
+
+def _mat(S, t=Type.FP64):
+    return Matrix.from_scipy(S, type=t, by_row=False)
+
+
+def test_hashed_and_direct_panels(gba):
+    """deg > one search step, hub runs longer than a wave, sparse and dense index ranges."""
+    As, Bs = _heavy_pair(60000, 6, 5000, 12, 20000, 3, seed=1)
+    A, B = _mat(As), _mat(Bs)
+    got, rep = _run(gba, A, B, "PLUS_TIMES_FP64")
+    want = oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64")
+    assert rep.bin_vectors[3] == 6 and rep.panels > 6 and np.diff(want.p).min() > 8192
+    assert_same(got, want, exact=True)
+
+
+def test_fully_dense_vectors_use_direct_panels(gba):
+    As, Bs = _heavy_pair(20000, 3, 300, 4, 5000, 2, seed=2, dense_cols=2)
+    dense_k = np.flatnonzero(np.diff(As.indptr) == 20000)
+    extra = sp.coo_matrix((np.ones(len(dense_k) * 3), (np.tile(dense_k, 3), np.repeat(np.arange(3), len(dense_k)))),
+                          shape=Bs.shape)
+    Bs = (Bs + extra).tocsc()                                     # every B(:,j) names the dense columns of A
+    A, B = _mat(As), _mat(Bs)
+    got, rep = _run(gba, A, B, "PLUS_TIMES_FP64")
+    want = oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64")
+    assert np.all(np.diff(want.p) == 20000)
+    assert_same(got, want, exact=True)
+
+
+def test_several_symbolic_panels(gba):
+    """vlen above the width of one symbolic bitmap panel: boundaries carry over panel edges."""
+    n = 1_700_000
+    As, Bs = _heavy_pair(n, 3, 30000, 6, 150000, 2, seed=3)
+    A, B = _mat(As), _mat(Bs)
+    got, rep = _run(gba, A, B, "PLUS_TIMES_FP64")
+    want = oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64")
+    assert rep.bin_vectors[3] == 3 and np.diff(want.p).min() > 100000
+    assert_same(got, want, exact=True)
+
+
+@pytest.mark.parametrize("sr,t", [
+    ("PLUS_TIMES_INT8", Type.INT8), ("PLUS_TIMES_UINT16", Type.UINT16), ("PLUS_TIMES_FP32", Type.FP32),
+    ("MIN_PLUS_FP64", Type.FP64), ("MAX_MIN_INT32", Type.INT32), ("LOR_LAND_BOOL", Type.BOOL),
+    ("PLUS_PAIR_INT64", Type.INT64), ("MIN_FIRSTJ_INT64", Type.INT64), ("MAX_SECONDI_INT32", Type.INT32),
+    ("BXOR_BAND_UINT32", Type.UINT32), ("TIMES_PLUS_INT64", Type.INT64), ("PLUS_ISGE_FP64", Type.FP64),
+])
+def test_semirings_on_heavy_vectors(gba, sr, t):
+    As, Bs = _heavy_pair(30000, 3, 2500, 8, 9000, 3, seed=4)
+    A, B = _mat(As, t), _mat(Bs, t)
+    got, rep = _run(gba, A, B, sr)
+    assert rep.bin_vectors[3] == 3
+    assert_same(got, oracle.saxpy3(None, False, False, A, B, sr), exact=True, what=sr)
+
+
+def test_any_monoid_on_heavy_vectors(gba):
+    As, Bs = _heavy_pair(30000, 2, 2500, 8, 9000, 3, seed=5)
+    A, B = _mat(As, Type.INT64), _mat(Bs, Type.INT64)
+    got, _ = _run(gba, A, B, "ANY_FIRSTJ_INT64")
+    want = oracle.saxpy3(None, False, False, A, B, "ANY_FIRSTJ_INT64")
+    assert_same(got, want, check_values=False)
+    # each value k must be a witness: A(i,k) and B(k,j) both present
+    r, c, v = got.coo()
+    Ap, Bp = (As != 0).tocsr(), (Bs != 0).tocsc()
+    for i, j, k in zip(r[::997], c[::997], v[::997]):
+        assert Ap[i, k] and Bp[k, j]
+
+
+@pytest.mark.parametrize("comp", [False, True])
+@pytest.mark.parametrize("mkind", ["sparse", "bitmap"])
+def test_masked_heavy_vectors(gba, mkind, comp):
+    n = 30000
+    As, Bs = _heavy_pair(n, 3, 2500, 8, 9000, 3, seed=6)
+    A, B = _mat(As), _mat(Bs)
+    rng = np.random.default_rng(8)
+    if mkind == "sparse":
+        Ms = sp.random(n, 3, density=0.5, random_state=rng, format="csc")
+        Ms.data = rng.integers(0, 2, len(Ms.data)).astype(np.float64)
+        M = Matrix.from_scipy(Ms, type=Type.INT8, by_row=False)
+    else:
+        M = Matrix.dense(rng.integers(0, 2, (n, 3)).astype(np.int8), present=rng.random((n, 3)) < 0.7, by_row=False)
+    got, rep = _run(gba, A, B, "PLUS_TIMES_FP64", M=M, comp=comp, struct=False)
+    want = oracle.saxpy3(M, comp, False, A, B, "PLUS_TIMES_FP64")
+    assert np.diff(want.p).max() > 4096
+    assert_same(got, want, exact=True)
+
+
+def test_jumbled_A_takes_the_dense_accumulator_path(gba):
+    """The panel sweep needs sorted A(:,k); a jumbled A must still give the same C."""
+    As, Bs = _heavy_pair(30000, 2, 2500, 8, 9000, 3, seed=7)
+    A, B = _mat(As), _mat(Bs)
+    want = oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64")
+    rng = np.random.default_rng(1)
+    for k in range(A.vdim):                                       # shuffle inside every vector
+        lo, hi = A.p[k], A.p[k + 1]
+        perm = rng.permutation(hi - lo)
+        A.i[lo:hi] = A.i[lo:hi][perm]; A.x[lo:hi] = A.x[lo:hi][perm]
+    A.jumbled = True
+    got, rep = _run(gba, A, B, "PLUS_TIMES_FP64")
+    assert rep.panels == 0
+    assert_same(got, want, exact=True)
+
+
+def test_rmat15_square_checksum_and_pattern(gba):
+    """RMAT-15 squared (tens of millions of entries in C, many heavy vectors): checksum identity,
+    entry count and no duplicates."""
+    A = gen.rmat(15, 16, seed=42, by_row=False, values="int")
+    dA = A.to_device()
+    out, rep, _ = gba.AxB_saxpy3(None, False, True, dA, dA, "PLUS_TIMES_FP64")
+    assert rep.panels > 1000
+    got = out.to_host(); out.free(); dA.free()
+    S = sp.csc_matrix((A.x, A.i, A.p), shape=(A.vlen, A.vdim))
+    colsum = np.asarray(S.sum(axis=0)).ravel(); rowsum = np.asarray(S.sum(axis=1)).ravel()
+    assert float(got.x.sum()) == float((colsum * rowsum).sum())
+    pat = (S != 0).astype(np.int64)
+    want_nnz = (pat @ pat).nnz
+    assert got.nvals == want_nnz == got.p[-1]
+    vec = np.repeat(np.arange(got.vdim), np.diff(got.p))
+    assert len(np.unique(vec * got.vlen + got.i)) == got.nvals
