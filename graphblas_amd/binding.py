@@ -104,6 +104,7 @@ class gba_report(C.Structure):
                 ("done_in_place", C.c_int32), ("a_transposed", C.c_int32), ("b_transposed", C.c_int32),
                 ("flops", C.c_int64), ("kernel_ms", C.c_double), ("phase_ms", C.c_double * 8),
                 ("bin_vectors", C.c_int64 * 4), ("bin_cnz", C.c_int64 * 4), ("bin_bnz", C.c_int64 * 4),
+                ("bin_madds", C.c_int64 * 4),
                 ("panels", C.c_int64), ("panels_redone", C.c_int64), ("cnz", C.c_int64)]
 
 

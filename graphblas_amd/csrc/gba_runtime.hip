@@ -352,28 +352,35 @@ gba_info stage_to_device(const gba_matrix *in, gba_matrix *out, std::vector<void
 // hipFree of a multi-gigabyte block unmaps its pages and can stall for most of
 // a second; outputs of that size are produced and dropped on every call of a
 // graph algorithm's inner loop.  Freed blocks are therefore kept, sorted by
-// capacity, and handed out again to requests they fit with at most 2x slack
+// capacity, and handed out again (best fit) to requests they fit with at most 2x slack
 // (the role the RMM pool plays for the reference's CUDA build,
 // rmm_wrap/rmm_wrap.h:76-83).  Blocks are reused in stream order: a block may
 // be given back while kernels that touch it are still queued on the library
 // stream, because whatever uses it next is queued behind them.
 class Pool {
+    struct Idle { void *p; uint64_t stamp; };
     std::mutex mu_;
-    std::multimap<size_t, void *> idle_;              // capacity -> block
+    std::multimap<size_t, Idle> idle_;                // capacity -> block
     std::unordered_map<void *, size_t> capacity_;     // every block this pool created and has not released
     size_t cached_ = 0, live_ = 0, limit_ = (size_t)8 << 30;
+    uint64_t clock_ = 0;
 
+    // capacities keep four significant bits, so requests of similar size share blocks
     static size_t round_up(size_t n) {
-        const size_t q = (n < ((size_t)1 << 20)) ? 512 : ((size_t)2 << 20);
+        if (n < 4096) return (n + 511) / 512 * 512;
+        int top = 63 - __builtin_clzll((unsigned long long)n);
+        const size_t q = (size_t)1 << (top - 3);
         return (n + q - 1) / q * q;
     }
-    void release_locked(size_t keep) {                // largest first
+    void release_locked(size_t keep) {                // least recently returned first
         while (cached_ > keep && !idle_.empty()) {
-            auto it = std::prev(idle_.end());
-            (void)hipFree(it->second);
-            capacity_.erase(it->second);
-            cached_ -= it->first;
-            idle_.erase(it);
+            auto victim = idle_.begin();
+            for (auto it = idle_.begin(); it != idle_.end(); ++it)
+                if (it->second.stamp < victim->second.stamp) victim = it;
+            (void)hipFree(victim->second.p);
+            capacity_.erase(victim->second.p);
+            cached_ -= victim->first;
+            idle_.erase(victim);
         }
     }
 
@@ -383,7 +390,7 @@ public:
         std::lock_guard<std::mutex> lock(mu_);
         auto it = idle_.lower_bound(cap);
         if (it != idle_.end() && it->first <= 2 * cap) {
-            void *p = it->second;
+            void *p = it->second.p;
             cached_ -= it->first; live_ += it->first;
             idle_.erase(it);
             return p;
@@ -406,7 +413,7 @@ public:
         const size_t cap = it->second;
         live_ -= cap;
         if (cap > limit_) { (void)hipFree(p); capacity_.erase(it); return; }
-        idle_.emplace(cap, p);
+        idle_.emplace(cap, Idle{p, ++clock_});
         cached_ += cap;
         if (cached_ > limit_) release_locked(limit_);
     }
@@ -446,7 +453,7 @@ gba_info gba_init(int device) {
     c.device = device;
     c.inited = true;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) pool().set_limit(total_b / 2);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) pool().set_limit(total_b / 2 + total_b / 8);
     if (const char *e = getenv("GBA_POOL_LIMIT_MB")) pool().set_limit((size_t)strtoull(e, nullptr, 10) << 20);
     return GBA_SUCCESS;
 }

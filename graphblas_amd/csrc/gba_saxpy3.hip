@@ -251,21 +251,24 @@ static gba_info build_bins(int64_t nvec, const int64_t *work, bool ptr_diff, Bin
     return GBA_SUCCESS;
 }
 
-// totals of nnz C(:,j) and nnz B(:,j) over one bin (reporting only)
+// totals of nnz C(:,j), nnz B(:,j) and multiply-adds over one bin (reporting only)
 __global__ void __launch_bounds__(256)
 bin_stats_kernel(int64_t nlist, const int64_t *__restrict__ list, const int64_t *__restrict__ Cp,
-                 const int64_t *__restrict__ Bp, unsigned long long *__restrict__ out /* [2] */) {
+                 const int64_t *__restrict__ Bp, const int64_t *__restrict__ vflops,
+                 unsigned long long *__restrict__ out /* [3] */) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    unsigned long long c = 0, b = 0;
+    unsigned long long c = 0, b = 0, f = 0;
     for (; idx < nlist; idx += stride) {
         const int64_t j = list[idx];
+        const unsigned long long bj = (unsigned long long)(Bp[j + 1] - Bp[j]);
         c += (unsigned long long)(Cp[j + 1] - Cp[j]);
-        b += (unsigned long long)(Bp[j + 1] - Bp[j]);
+        b += bj;
+        f += (unsigned long long)vflops[j] - bj;        // the flop count includes nnz B(:,j) itself
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { c += __shfl_down(c, d, 64); b += __shfl_down(b, d, 64); }
-    if ((threadIdx.x & 63) == 0) { if (c) atomicAdd(&out[0], c); if (b) atomicAdd(&out[1], b); }
+    for (int d = 32; d > 0; d >>= 1) { c += __shfl_down(c, d, 64); b += __shfl_down(b, d, 64); f += __shfl_down(f, d, 64); }
+    if ((threadIdx.x & 63) == 0) { if (c) atomicAdd(&out[0], c); if (b) atomicAdd(&out[1], b); if (f) atomicAdd(&out[2], f); }
 }
 
 // ------------------------------------------------------------- LDS hashing --
@@ -1437,19 +1440,22 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         rep->bin_vectors[0] = P.num.count[BIN_WAVE]; rep->bin_vectors[1] = P.num.count[BIN_BLK1];
         rep->bin_vectors[2] = P.num.count[BIN_BLK2]; rep->bin_vectors[3] = P.num.count[BIN_GLOBAL];
         rep->panels = (int64_t)P.panel_stats[1]; rep->panels_redone = (int64_t)P.panel_stats[2];
-        DevBuf bs; GBA_OK(bs.alloc(8 * 8));
-        GBA_HIP(hipMemsetAsync(bs.p, 0, 64, st));
+        DevBuf bs; GBA_OK(bs.alloc(12 * 8));
+        GBA_HIP(hipMemsetAsync(bs.p, 0, 96, st));
         for (int b = 0; b < 4; b++) {
             const int64_t cntb = P.num.count[BIN_WAVE + b];
             if (cntb == 0) continue;
             int64_t blocks = ceil_div(cntb, 256); if (blocks > 1024) blocks = 1024;
             hipLaunchKernelGGL(bin_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cntb, P.num.list(BIN_WAVE + b),
-                               Cp.as<int64_t>(), B->p, bs.as<unsigned long long>() + 2 * b);
+                               Cp.as<int64_t>(), B->p, vflops.as<int64_t>(), bs.as<unsigned long long>() + 3 * b);
         }
-        unsigned long long hs[8];
-        GBA_HIP(hipMemcpyAsync(hs, bs.p, 64, hipMemcpyDeviceToHost, st));
+        unsigned long long hs[12];
+        GBA_HIP(hipMemcpyAsync(hs, bs.p, 96, hipMemcpyDeviceToHost, st));
         GBA_HIP(hipStreamSynchronize(st));
-        for (int b = 0; b < 4; b++) { rep->bin_cnz[b] = (int64_t)hs[2 * b]; rep->bin_bnz[b] = (int64_t)hs[2 * b + 1]; }
+        for (int b = 0; b < 4; b++) {
+            rep->bin_cnz[b] = (int64_t)hs[3 * b]; rep->bin_bnz[b] = (int64_t)hs[3 * b + 1];
+            rep->bin_madds[b] = (int64_t)hs[3 * b + 2];
+        }
     }
 
     C->vlen = A->vlen; C->vdim = B->vdim; C->nvec = nvec; C->nvals = cnz;

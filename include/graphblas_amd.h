@@ -168,11 +168,12 @@ typedef struct gba_report {
     double  kernel_ms;      /* device time of the whole method (HIP events on the library stream) */
     /* saxpy3 only: device time per phase, HIP events on the library stream.
      * [0] flop count + binning  [1] symbolic  [2] numeric binning + cumsum + allocation
-     * [3] numeric wave bin  [4] numeric block bin 1  [5] numeric block bin 2  [6] numeric global bin  [7] sort */
+     * [3] numeric wave bin  [4] numeric block bin 1  [5] numeric block bin 2  [6] numeric heavy-vector (panel) bin  [7] sort */
     double  phase_ms[8];
     int64_t bin_vectors[4]; /* saxpy3 numeric: vectors routed to wave / block1 / block2 / global bins */
     int64_t bin_cnz[4];     /* entries of C those vectors hold                                        */
     int64_t bin_bnz[4];     /* entries of B those vectors hold                                        */
+    int64_t bin_madds[4];   /* multiply-adds those vectors take                                       */
     int64_t panels;         /* saxpy3 numeric, heavy vectors: LDS panels swept, and panels redone at   */
     int64_t panels_redone;  /* half width after a table overflow                                      */
     int64_t cnz;            /* entries produced (saxpy3, dot3) */
@@ -194,7 +195,7 @@ void     gba_free(void *p);
 /* gba_free keeps blocks for reuse by later gba_malloc calls (hipFree of a
  * multi-gigabyte block stalls for hundreds of ms); the reference's CUDA build
  * gets the same from its RMM pool (rmm_wrap/rmm_wrap.h:53-83).  The pool holds
- * at most `limit` idle bytes (default: half of the device memory, or
+ * at most `limit` idle bytes (default: 5/8 of the device memory, or
  * GBA_POOL_LIMIT_MB), and is emptied before an allocation is reported failed. */
 gba_info gba_pool_set_limit(size_t nbytes);
 gba_info gba_pool_release(void);           /* hipFree every idle block now */
