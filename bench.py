@@ -172,7 +172,8 @@ def main():
             "phase_ms_per_step_rank0": [round(float(x) / args.steps, 3) for x in stats["phase_ms"]],
             "numeric_bin_vectors_rank0": [int(x) // max(args.steps, 1) for x in stats["bins"]],
             "roofline": {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": measured_traffic(f"RMAT-{args.scale} ef={args.edge_factor}", names[k]),
                          "avg_launch_ms": round(float(k_ms), 3), "algorithmic_bytes_per_launch": int(k_bytes),
                          "streaming_model_GBps": round(streamed, 2),
                          "kernel_multiply_adds_per_launch": int(stats["bin_madds"][k] // launches)},
@@ -185,6 +186,17 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/hbm_traffic.json); None when this workload has not been profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            rec = json.load(f).get(workload)
+        return int(rec["traffic"]) if rec and rec["kernel"] == kernel else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(A, rf, target_madds):
