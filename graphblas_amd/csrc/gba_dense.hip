@@ -153,6 +153,107 @@ dot_long_kernel(S sr, const int64_t *__restrict__ Ap, const int64_t *__restrict_
     }
 }
 
+// Entry-balanced version for monoids with a hardware-sized accumulator and multipliers that do not
+// use the row index: every workgroup takes DOT_TILE consecutive ENTRIES of A (coalesced loads of
+// Ai/Ax whatever the row lengths are -- RMAT rows range from 0 to 10^5 entries), puts the products
+// in LDS, finds the rows its tile touches by bisection of Ap and reduces each row segment from LDS.
+// A row that continues into a neighbouring tile is combined with the monoid's atomic.
+// MODE 1 expects Cb zeroed and Cx filled with the monoid identity.
+static constexpr int DOT_TILE_THREADS = 256, DOT_TILE_ITEMS = 8, DOT_TILE = DOT_TILE_THREADS * DOT_TILE_ITEMS;
+template <class ACC> __global__ void fill_kernel(ACC *p, int64_t n, ACC v);
+
+template <class S, int MODE>
+__device__ inline void dot_commit(const S &sr, const MaskViewD &M, int64_t i, int64_t j, int64_t cvlen,
+                                  typename S::z_t acc, bool shared, typename S::z_t *__restrict__ Cx,
+                                  int8_t *__restrict__ Cb) {
+    if (MODE == 1 && !maskd_allows(M, i, j)) return;
+    const int64_t pC = j * cvlen + i;
+    if (shared) sr.atomic(&Cx[pC], acc);
+    else Cx[pC] = (MODE == 0) ? sr.add(Cx[pC], acc) : acc;
+    if (MODE == 1) Cb[pC] = 1;
+}
+
+template <class S, int MODE>
+__global__ void __launch_bounds__(DOT_TILE_THREADS)
+dot_tile_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                const void *__restrict__ Ax_, bool A_iso, DenseView B, MaskViewD M,
+                typename S::z_t *__restrict__ Cx, int8_t *__restrict__ Cb, int64_t cvlen) {
+    using X = typename S::x_t; using Z = typename S::z_t;
+    __shared__ Z prod[DOT_TILE];
+    __shared__ uint8_t have[DOT_TILE];
+    __shared__ Z part[DOT_TILE_THREADS / 64];
+    __shared__ int pfound[DOT_TILE_THREADS / 64];
+    const X *Ax = reinterpret_cast<const X *>(Ax_);
+    const X *Bx = reinterpret_cast<const X *>(B.x);
+    const int tid = threadIdx.x;
+    const int64_t j = blockIdx.y;
+    const int64_t pN = Ap[nvecA];
+    const int64_t start = Ap[0] + (int64_t)blockIdx.x * DOT_TILE;
+    if (start >= pN) return;                                  // uniform
+    const int64_t end = (start + DOT_TILE < pN) ? start + DOT_TILE : pN;
+    // r0 = row holding the first entry of the tile = largest r with Ap[r] <= start.  The 256 threads
+    // probe 256 evenly spaced rows per round (three rounds for 2^24 rows) instead of bisecting.
+    int64_t r0;
+    {
+        int64_t lo = 0, hi = nvecA - 1;                       // candidates, inclusive
+        while (lo < hi) {
+            const int64_t span = hi - lo;                     // probes lo+1 .. hi, non-decreasing in tid
+            const int64_t probe = lo + 1 + (span - 1) * tid / (DOT_TILE_THREADS - 1);
+            const int c = __syncthreads_count(Ap[probe] <= start);     // monotone: the first c threads
+            const int64_t below = (c > 0) ? lo + 1 + (span - 1) * (c - 1) / (DOT_TILE_THREADS - 1) : lo;
+            const int64_t above = (c < DOT_TILE_THREADS) ? lo + 1 + (span - 1) * c / (DOT_TILE_THREADS - 1) : hi + 1;
+            lo = below; hi = above - 1;
+        }
+        r0 = lo;
+    }
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    const int64_t boff = j * B.vlen;
+#pragma unroll
+    for (int it = 0; it < DOT_TILE_ITEMS; it++) {
+        const int idx = it * DOT_TILE_THREADS + tid;
+        const int64_t p = start + idx;
+        if (p < end) {
+            const int64_t k = Ai[p];
+            const bool ok = !B.b || B.b[boff + k];
+            Z t = Z();
+            if (ok) t = sr.mult(load_x<X>(Ax, p, A_iso, apat), load_x<X>(Bx, boff + k, B.iso, bpat), 0, k, j);
+            prod[idx] = t;
+            have[idx] = ok;
+        }
+    }
+    __syncthreads();
+    if (Ap[r0 + 1] >= end) {                                  // the tile lies inside one long row
+        Z acc = sr.identity(); int found = 0;
+        for (int idx = tid; idx < (int)(end - start); idx += DOT_TILE_THREADS)
+            if (have[idx]) { acc = found ? sr.add(acc, prod[idx]) : prod[idx]; found = 1; }
+        group_reduce(sr, acc, found, 64);
+        if ((tid & 63) == 0) { part[tid >> 6] = acc; pfound[tid >> 6] = found; }
+        __syncthreads();
+        if (tid == 0) {
+            Z r = sr.identity(); int f = 0;
+            for (int w = 0; w < DOT_TILE_THREADS / 64; w++) if (pfound[w]) { r = f ? sr.add(r, part[w]) : part[w]; f = 1; }
+            const bool shared = Ap[r0] < start || Ap[r0 + 1] > end;
+            if (f) dot_commit<S, MODE>(sr, M, r0, j, cvlen, r, shared, Cx, Cb);
+        }
+        return;
+    }
+    for (int64_t r = r0 + tid; r < nvecA; r += DOT_TILE_THREADS) {
+        const int64_t a0 = Ap[r], a1 = Ap[r + 1];
+        if (a0 >= end) break;                                 // past the last row of the tile
+        const int lo = (int)((a0 > start ? a0 : start) - start), hi = (int)((a1 < end ? a1 : end) - start);
+        Z acc = sr.identity(); int found = 0;
+        for (int idx = lo; idx < hi; idx++)
+            if (have[idx]) { acc = found ? sr.add(acc, prod[idx]) : prod[idx]; found = 1; }
+        if (found) dot_commit<S, MODE>(sr, M, r, j, cvlen, acc, a0 < start || a1 > end, Cx, Cb);
+    }
+}
+
+// does the semiring fit dot_tile_kernel?
+template <class S> struct dot_tile_ok {
+    static constexpr bool v = !S::positional && sizeof(typename S::z_t) >= 4 &&
+                              std::is_same<typename S::z_t, typename S::acc_t>::value;
+};
+
 static gba_info count_ones(const int8_t *b, int64_t n, int64_t *out) { return dev_count_ones(b, n, out); }
 
 static int pick_group(const gba_matrix *A) {
@@ -198,6 +299,24 @@ static gba_info dot_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask_c
         int8_t *cb = (MODE == 0) ? nullptr : Cb.as<int8_t>();
         GBA_OK(with_semiring(c, [&](auto sr) -> gba_info {
             using S = decltype(sr); using Z = typename S::z_t;
+            if constexpr (dot_tile_ok<S>::v) {
+                if (A->nvals > 0) {
+                    const int64_t cn = cvlen * cvdim;
+                    if (MODE == 1) {
+                        GBA_HIP(hipMemsetAsync(cb, 0, (size_t)cn, st));
+                        int64_t fb = ceil_div(cn, 256); if (fb > 8192) fb = 8192;
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(fill_kernel<Z>), dim3((unsigned)fb), dim3(256), 0, st,
+                                           reinterpret_cast<Z *>(cx), cn, sr.identity());
+                    }
+                    dim3 tgrid((unsigned)ceil_div(A->nvals, DOT_TILE), (unsigned)cvdim);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(dot_tile_kernel<S, MODE>), tgrid, dim3(DOT_TILE_THREADS), 0, st, sr,
+                                       A->nvec, A->p, A->i, A->x, A->iso, Bv, mv, reinterpret_cast<Z *>(cx), cb, cvlen);
+                } else if (MODE == 1) {
+                    GBA_HIP(hipMemsetAsync(cb, 0, (size_t)(cvlen * cvdim), st));
+                }
+                GBA_HIP(hipGetLastError());
+                return GBA_SUCCESS;
+            }
             dim3 grid((unsigned)ceil_div(A->nvec * lpr, 256), (unsigned)cvdim);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(dot_sd_kernel<S, MODE>), grid, dim3(256), 0, st, sr, A->nvec, A->p, A->i,
                                A->x, A->iso, Bv, mv, lpr, long_len, reinterpret_cast<Z *>(cx), cb, cvlen,

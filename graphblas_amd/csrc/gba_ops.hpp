@@ -326,6 +326,7 @@ template <class XT, class ZT> struct mult_kind {
 template <class XT, class ZT, int KIND>
 struct Srt {
     using x_t = XT; using z_t = ZT; using acc_t = typename acc_of<ZT>::type;
+    static constexpr bool positional = (KIND == KIND_POS);   // the multiplier reads i, k or j
     int add_op, mult_op;
     bool a_pattern, b_pattern;
     __host__ __device__ bool a_is_pattern() const { return a_pattern; }
@@ -346,6 +347,7 @@ template <int ADD, int MULT, class XT, class ZT>
 struct Sct {
     using x_t = XT; using z_t = ZT; using acc_t = typename acc_of<ZT>::type;
     static constexpr bool POS = (MULT >= GBA_FIRSTI && MULT <= GBA_SECONDJ1);
+    static constexpr bool positional = POS;
     __host__ __device__ bool a_is_pattern() const { return POS || MULT == GBA_SECOND || MULT == GBA_PAIR; }
     __host__ __device__ bool b_is_pattern() const { return POS || MULT == GBA_FIRST || MULT == GBA_PAIR; }
     __device__ ZT mult(XT a, XT b, int64_t i, int64_t k, int64_t j) const {

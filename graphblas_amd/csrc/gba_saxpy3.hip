@@ -687,6 +687,7 @@ struct PanelSegs {
     unsigned long long where[PANEL_SEGCAP];   // position of the run in A (high 40 bits) | neighbour ordinal (low 24)
     uint32_t off[PANEL_SEGCAP];               // run length; exclusive prefix sum once the runs are expanded
     uint32_t wsum[PANEL_THREADS / 64];
+    unsigned long long wmask[PANEL_THREADS / 64][PANEL_UNROLL];   // per wave: products of the window at which a run starts
     int nseg;
     int more;                                 // some neighbour still has entries below the end of the sweep
     int overflow;                             // the numeric table ran out of room
@@ -713,10 +714,9 @@ __device__ inline int64_t first_ge(const int64_t *__restrict__ X, int64_t lo, in
 }
 
 // Expand the n queued runs: they are laid end to end (prefix sum of their
-// lengths) and the threads take the products round-robin, PANEL_UNROLL at a
-// time so that the loads of several products are in flight together; each
-// product finds its run by bisection of the prefix sums, so the work is even
-// however skewed the runs are.  load(i, pA, pB) fetches what one product
+// lengths) and cut into equal slabs of products, one per wave, PANEL_UNROLL
+// products per lane in flight together, so the work is even however skewed
+// the runs are.  load(i, pA, pB) fetches what one product
 // needs; apply(i[], payload[], ok[]) consumes a batch of PANEL_UNROLL.  Needs a barrier between the last
 // append and the call; ends on a barrier with the queue empty.
 template <class Load, class Apply>
@@ -741,37 +741,76 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
     if (tid == 0) S->nseg = 0;
     __syncthreads();
     const int64_t *__restrict__ Ai = A.i;
-    int top = 1;                                        // largest power of two below n (bisection stride)
-    while (top * 2 < n) top <<= 1;
-    for (int64_t p0 = tid; p0 < (int64_t)T; p0 += (int64_t)PANEL_UNROLL * PANEL_THREADS) {
-        uint32_t pp[PANEL_UNROLL]; bool ok[PANEL_UNROLL]; int seg[PANEL_UNROLL];
-#pragma unroll
-        for (int u = 0; u < PANEL_UNROLL; u++) {
-            const int64_t p = p0 + (int64_t)u * PANEL_THREADS;
-            ok[u] = p < (int64_t)T;
-            pp[u] = ok[u] ? (uint32_t)p : (T - 1);
-            seg[u] = 0;
-        }
+    // Each wave owns a contiguous slab of windows of WIN consecutive products.  It bisects the
+    // prefix sums once, for the run holding its first product; after that the runs that START
+    // inside a window are read 64 at a time (one conflict-free LDS read), marked in WIN bits, and
+    // a product's run is the window's first run plus the number of marks at or before it.
+    constexpr uint32_t WIN = 64 * PANEL_UNROLL;
+    constexpr int NWAVES = PANEL_THREADS / 64;
+    const uint32_t nwin = (uint32_t)(((uint64_t)T + WIN - 1) / WIN);
+    const uint32_t per = (nwin + NWAVES - 1) / NWAVES;
+    uint32_t win = (uint32_t)wv * per;
+    const uint32_t win_end = (win + per < nwin) ? win + per : nwin;
+    if (win < win_end) {
+        uint64_t w0 = (uint64_t)win * WIN;
+        int top = 1;                                    // largest power of two below n (bisection stride)
+        while (top * 2 < n) top <<= 1;
+        int sb = 0;                                     // run holding product w0: largest s with off[s] <= w0
         for (int step = top; step > 0; step >>= 1) {
+            const int idx = sb + step;
+            if (idx < n && (uint64_t)S->off[idx] <= w0) sb = idx;
+        }
+        unsigned long long *wm = S->wmask[wv];
+        for (; win < win_end; win++, w0 += WIN) {
+            const uint64_t wend = w0 + WIN;
+            if (lane < PANEL_UNROLL) wm[lane] = 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            bool edge = false;                          // a run starts exactly at the next window
+            for (int cursor = sb + 1;; cursor += 64) {
+                const int idx = cursor + lane;
+                const uint64_t o = (idx < n) ? (uint64_t)S->off[idx] : ~0ull;
+                const bool in = o < wend;               // off[] is strictly increasing and off[sb + 1] > w0
+                if (in) { const uint32_t q = (uint32_t)(o - w0); atomicOr(&wm[q >> 6], 1ull << (q & 63)); }
+                if (__ballot(o == wend)) edge = true;
+                if (__ballot(in) != ~0ull) break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            unsigned long long mk[PANEL_UNROLL];
+            int starts = 0;
+#pragma unroll
+            for (int u = 0; u < PANEL_UNROLL; u++) { mk[u] = ((volatile unsigned long long *)wm)[u]; starts += __builtin_popcountll(mk[u]); }
+            uint32_t pp[PANEL_UNROLL]; bool ok[PANEL_UNROLL]; int seg[PANEL_UNROLL];
+            const uint32_t lastx = (uint32_t)((uint64_t)T - 1 - w0);      // last product of the window if it is the last window
 #pragma unroll
             for (int u = 0; u < PANEL_UNROLL; u++) {
-                const int idx = seg[u] + step;
-                if (idx < n && S->off[idx] <= pp[u]) seg[u] = idx;
+                uint32_t x = (uint32_t)u * 64 + (uint32_t)lane;
+                ok[u] = w0 + x < (uint64_t)T;
+                if (!ok[u]) x = lastx;
+                const int xu = (int)(x >> 6), xl = (int)(x & 63);
+                int cnt = 0;
+#pragma unroll
+                for (int q = 0; q < PANEL_UNROLL; q++) {
+                    const unsigned long long bits = (q < xu) ? ~0ull : ((q == xu) ? (~0ull >> (63 - xl)) : 0ull);
+                    cnt += __builtin_popcountll(mk[q] & bits);
+                }
+                seg[u] = sb + cnt;
+                pp[u] = (uint32_t)(w0 + x);
             }
+            int64_t pA[PANEL_UNROLL], pB[PANEL_UNROLL], ii[PANEL_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PANEL_UNROLL; u++) {
+                const unsigned long long w = S->where[seg[u]];
+                pA[u] = (int64_t)(w >> PANEL_T_BITS) + (int64_t)(pp[u] - S->off[seg[u]]);
+                pB[u] = pB0 + (int64_t)(w & (unsigned long long)(PANEL_MAX_DEG - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < PANEL_UNROLL; u++) ii[u] = Ai[pA[u]];
+            decltype(load(ii[0], pA[0], pB[0])) payload[PANEL_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PANEL_UNROLL; u++) payload[u] = load(ii[u], pA[u], pB[u]);
+            apply(ii, payload, ok);
+            sb += starts + (edge ? 1 : 0);
         }
-        int64_t pA[PANEL_UNROLL], pB[PANEL_UNROLL], ii[PANEL_UNROLL];
-#pragma unroll
-        for (int u = 0; u < PANEL_UNROLL; u++) {
-            const unsigned long long w = S->where[seg[u]];
-            pA[u] = (int64_t)(w >> PANEL_T_BITS) + (int64_t)(pp[u] - S->off[seg[u]]);
-            pB[u] = pB0 + (int64_t)(w & (unsigned long long)(PANEL_MAX_DEG - 1));
-        }
-#pragma unroll
-        for (int u = 0; u < PANEL_UNROLL; u++) ii[u] = Ai[pA[u]];
-        decltype(load(ii[0], pA[0], pB[0])) payload[PANEL_UNROLL];
-#pragma unroll
-        for (int u = 0; u < PANEL_UNROLL; u++) payload[u] = load(ii[u], pA[u], pB[u]);
-        apply(ii, payload, ok);
     }
     __syncthreads();
 }
