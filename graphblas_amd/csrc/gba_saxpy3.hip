@@ -25,6 +25,7 @@ namespace gba {
 // ------------------------------------------------------------------- views --
 struct SpView {                 // sparse operand
     const int64_t *p; const int64_t *i; const void *x; bool iso;
+    const int32_t *i32;         // the same indices in 32 bits (panel kernels only; vlen < 2^31), or null
 };
 struct MaskView {
     int kind;                   // 0 none, 1 sparse, 2 bitmap, 3 full
@@ -665,7 +666,8 @@ static constexpr int PANEL_THREADS = 1024;
 static constexpr int PANEL_NPT = 2;                                   // neighbours searched per thread per step
 static constexpr int PANEL_STEP = PANEL_THREADS * PANEL_NPT;
 static constexpr int PANEL_SEGCAP = 4 * PANEL_THREADS;                // runs queued in LDS before they are expanded
-static constexpr int PANEL_UNROLL = 4;                                // products in flight per thread
+static constexpr int PANEL_UNROLL_MAX = 8;
+static constexpr int SYM_PANEL_UNROLL = 4, NUM_PANEL_UNROLL = 4;            // products in flight per thread
 static constexpr int PANEL_T_BITS = 24;
 static constexpr int64_t PANEL_MAX_DEG = (int64_t)1 << PANEL_T_BITS;
 static constexpr int64_t PANEL_MAX_WIDTH = (int64_t)1 << 20;          // (SEGCAP-1) runs of this length stay below 2^32
@@ -687,7 +689,7 @@ struct PanelSegs {
     unsigned long long where[PANEL_SEGCAP];   // position of the run in A (high 40 bits) | neighbour ordinal (low 24)
     uint32_t off[PANEL_SEGCAP];               // run length; exclusive prefix sum once the runs are expanded
     uint32_t wsum[PANEL_THREADS / 64];
-    unsigned long long wmask[PANEL_THREADS / 64][PANEL_UNROLL];   // per wave: products of the window at which a run starts
+    unsigned long long wmask[PANEL_THREADS / 64][PANEL_UNROLL_MAX];   // per wave: products of the window at which a run starts
     int nseg;
     int more;                                 // some neighbour still has entries below the end of the sweep
     int overflow;                             // the numeric table ran out of room
@@ -704,7 +706,7 @@ struct PanelCursors {
 };
 
 // first p in [lo,hi) with X[p] >= target (hi if none): gallop from lo, then bisect
-__device__ inline int64_t first_ge(const int64_t *__restrict__ X, int64_t lo, int64_t hi, int64_t target) {
+__device__ inline int64_t first_ge(const int32_t *__restrict__ X, int64_t lo, int64_t hi, int64_t target) {
     if (lo >= hi || X[lo] >= target) return lo;
     int64_t step = 1;
     while (lo + step < hi && X[lo + step] < target) { lo += step; step <<= 1; }
@@ -719,7 +721,7 @@ __device__ inline int64_t first_ge(const int64_t *__restrict__ X, int64_t lo, in
 // the runs are.  load(i, pA, pB) fetches what one product
 // needs; apply(i[], payload[], ok[]) consumes a batch of PANEL_UNROLL.  Needs a barrier between the last
 // append and the call; ends on a barrier with the queue empty.
-template <class Load, class Apply>
+template <int PANEL_UNROLL, class Load, class Apply>
 __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSegs *S, Load load, Apply apply) {
     static_assert(PANEL_SEGCAP == 4 * PANEL_THREADS, "four queue entries per thread in the scan");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -740,7 +742,7 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
     for (int q = 0; q < 4; q++) if (b4 + q < n) { S->off[b4 + q] = run; run += v[q]; }
     if (tid == 0) S->nseg = 0;
     __syncthreads();
-    const int64_t *__restrict__ Ai = A.i;
+    const int32_t *__restrict__ Ai = A.i32;
     // Each wave owns a contiguous slab of windows of WIN consecutive products.  It bisects the
     // prefix sums once, for the run holding its first product; after that the runs that START
     // inside a window are read 64 at a time (one conflict-free LDS read), marked in WIN bits, and
@@ -796,7 +798,7 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
                 seg[u] = sb + cnt;
                 pp[u] = (uint32_t)(w0 + x);
             }
-            int64_t pA[PANEL_UNROLL], pB[PANEL_UNROLL], ii[PANEL_UNROLL];
+            int64_t pA[PANEL_UNROLL], pB[PANEL_UNROLL]; int32_t ii[PANEL_UNROLL];
 #pragma unroll
             for (int u = 0; u < PANEL_UNROLL; u++) {
                 const unsigned long long w = S->where[seg[u]];
@@ -823,12 +825,12 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
 // expanded whenever it might not hold another step.  The caller provides a
 // barrier between resetting S->more / S->overflow and the call; the call ends
 // on a barrier.  Returns early (on a barrier) once S->overflow is raised.
-template <class Load, class Apply>
+template <int PANEL_UNROLL, class Load, class Apply>
 __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0, int64_t deg, int64_t ibeg,
                                   int64_t pend, int64_t iend, bool first, const PanelCursors &pc, PanelSegs *S,
                                   Load load, Apply apply) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t *__restrict__ Ai = A.i;
+    const int32_t *__restrict__ Ai = A.i32;
     for (int64_t t0 = 0; t0 < deg; t0 += PANEL_STEP) {
         int64_t c[PANEL_NPT], e[PANEL_NPT], nv[PANEL_NPT], stop[PANEL_NPT];
         bool live[PANEL_NPT], need[PANEL_NPT];
@@ -871,7 +873,7 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
 #pragma unroll
             for (int q = 0; q < PANEL_NPT; q++) { lo[q] = c[q]; st[q] = 1; g[q] = need[q]; any |= g[q]; }
             while (any) {
-                int64_t pos[PANEL_NPT], xv[PANEL_NPT]; bool inb[PANEL_NPT];
+                int64_t pos[PANEL_NPT]; int32_t xv[PANEL_NPT]; bool inb[PANEL_NPT];
 #pragma unroll
                 for (int q = 0; q < PANEL_NPT; q++) {
                     pos[q] = lo[q] + st[q];
@@ -895,7 +897,7 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
                 any |= a[q] < b[q];
             }
             while (any) {
-                int64_t m[PANEL_NPT], xv[PANEL_NPT]; bool act[PANEL_NPT];
+                int64_t m[PANEL_NPT]; int32_t xv[PANEL_NPT]; bool act[PANEL_NPT];
 #pragma unroll
                 for (int q = 0; q < PANEL_NPT; q++) {
                     act[q] = a[q] < b[q];
@@ -939,12 +941,19 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
         const int ns = S->nseg;
         const bool last = t0 + PANEL_STEP >= deg;
         if (ns >= PANEL_SEGCAP - PANEL_STEP || (last && ns > 0)) {
-            panel_expand(A, pB0, ns, S, load, apply);
+            panel_expand<PANEL_UNROLL>(A, pB0, ns, S, load, apply);
             if (S->overflow) return;
         } else {
             __syncthreads();                                    // everyone has read nseg before the next append
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+narrow_index_kernel(const int64_t *__restrict__ in, int32_t *__restrict__ out, int64_t n) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx < n; idx += stride) out[idx] = (int32_t)in[idx];
 }
 
 // room[j] = boundaries vector j can have at most (0 for vectors the panel kernel does not count)
@@ -994,11 +1003,11 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
             const int64_t pend = (p == npanels - 1) ? PANEL_INF : base + SYM_PANEL_WIDTH;
             if (tid == 0) Q.more = 0;
             __syncthreads();
-            panel_walk(A, B, pB0, deg, 0, pend, PANEL_INF, p == 0, pc, &Q,
-                [](int64_t, int64_t, int64_t) { return 0; },
-                [&](const int64_t (&i)[PANEL_UNROLL], const int (&)[PANEL_UNROLL], const bool (&ok)[PANEL_UNROLL]) {
+            panel_walk<SYM_PANEL_UNROLL>(A, B, pB0, deg, 0, pend, PANEL_INF, p == 0, pc, &Q,
+                [](int32_t, int64_t, int64_t) { return 0; },
+                [&](const int32_t (&i)[SYM_PANEL_UNROLL], const int (&)[SYM_PANEL_UNROLL], const bool (&ok)[SYM_PANEL_UNROLL]) {
 #pragma unroll
-                    for (int u = 0; u < PANEL_UNROLL; u++) {
+                    for (int u = 0; u < SYM_PANEL_UNROLL; u++) {
                         if (!ok[u] || !mask_allows(M, i[u], j)) continue;
                         const uint32_t o = (uint32_t)(i[u] - base);
                         atomicOr(&bm[o >> 5], 1u << (o & 31));
@@ -1105,17 +1114,17 @@ num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
             const int64_t pend = (lim >= cvlen) ? PANEL_INF : lim;
             if (threadIdx.x == 0) { Q.overflow = 0; Q.more = 0; out_cursor = 0; }
             __syncthreads();
-            panel_walk(A, B, pB0, deg, 0, pend, PANEL_INF, first, pc, &Q,
-                [&](int64_t i, int64_t pA, int64_t pB) -> Z {
+            panel_walk<NUM_PANEL_UNROLL>(A, B, pB0, deg, 0, pend, PANEL_INF, first, pc, &Q,
+                [&](int32_t i, int64_t pA, int64_t pB) -> Z {
                     return product(sr, A, B, apat, bpat, i, B.i[pB], j, pA, pB);
                 },
-                [&](const int64_t (&i)[PANEL_UNROLL], const Z (&t)[PANEL_UNROLL], const bool (&ok)[PANEL_UNROLL]) {
-                    bool todo[PANEL_UNROLL];
+                [&](const int32_t (&i)[NUM_PANEL_UNROLL], const Z (&t)[NUM_PANEL_UNROLL], const bool (&ok)[NUM_PANEL_UNROLL]) {
+                    bool todo[NUM_PANEL_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < PANEL_UNROLL; u++) todo[u] = ok[u] && mask_allows(M, i[u], j);
+                    for (int u = 0; u < NUM_PANEL_UNROLL; u++) todo[u] = ok[u] && mask_allows(M, i[u], j);
                     if (direct) {
 #pragma unroll
-                        for (int u = 0; u < PANEL_UNROLL; u++) if (todo[u]) {
+                        for (int u = 0; u < NUM_PANEL_UNROLL; u++) if (todo[u]) {
                             const uint32_t h = (uint32_t)(i[u] - base);
                             keys[h] = (int32_t)i[u];
                             sr.atomic(&vals[h], t[u]);
@@ -1124,7 +1133,7 @@ num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
                     }
                     // open addressing, linear probing
 #pragma unroll
-                    for (int u = 0; u < PANEL_UNROLL; u++) if (todo[u]) {
+                    for (int u = 0; u < NUM_PANEL_UNROLL; u++) if (todo[u]) {
                         const int32_t key = (int32_t)i[u];
                         uint32_t h = panel_hash(key);
                         bool placed = false;
@@ -1418,16 +1427,35 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     // bound on nnz C(:,j) whatever the mask does, which is what sizes the hash tables.
     DevBuf vflops; GBA_OK(vflops.alloc((size_t)(nvec + 1) * 8));
     GBA_OK(saxpy3_flopcount(nullptr, vflops.as<int64_t>(), nullptr, false, A, B));
-    GBA_OK(build_bins(nvec, vflops.as<int64_t>(), false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, SYM_BLK2_MAX}, &P.sym));
+    // With sorted A the bitmap panel kernel also takes the vectors of the second block bin: it has no table to
+    // clear per vector and records the numeric panel boundaries.
+    const int64_t sym_blk2_max = A->jumbled ? SYM_BLK2_MAX : SYM_BLK1_MAX;
+    GBA_OK(build_bins(nvec, vflops.as<int64_t>(), false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, sym_blk2_max}, &P.sym));
     P.A_sorted = !A->jumbled;
     P.vflops = vflops.as<int64_t>();
     if (P.sym.count[BIN_GLOBAL] > 0) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
+    // the panel kernels read the indices of A from a 32-bit copy (vlen < 2^31 was checked above)
+    DevBuf ai32;
+    auto narrow_A = [&]() -> gba_info {
+        if (P.A.i32) return GBA_SUCCESS;
+        int64_t aend = 0;
+        GBA_OK(dev_read_i64(A->p + A->nvec, &aend));
+        GBA_OK(ai32.alloc((size_t)(aend > 0 ? aend : 1) * 4));
+        if (aend > 0) {
+            int64_t blocks = ceil_div(aend, 1024); if (blocks > 16384) blocks = 16384;
+            hipLaunchKernelGGL(narrow_index_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A->i, ai32.as<int32_t>(), aend);
+            GBA_HIP(hipGetLastError());
+        }
+        P.A.i32 = ai32.as<int32_t>();
+        return GBA_SUCCESS;
+    };
     DevBuf bstart, bounds;
     if (P.sym.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) {
+        GBA_OK(narrow_A());
         GBA_OK(bstart.alloc((size_t)(nvec + 1) * 8));
         int64_t blocks = ceil_div(nvec + 1, 256); if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(bounds_room_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, vflops.as<int64_t>(),
-                           P.cvlen, (int64_t)SYM_BLK2_MAX, bstart.as<int64_t>());
+                           P.cvlen, sym_blk2_max, bstart.as<int64_t>());
         GBA_HIP(hipGetLastError());
         GBA_OK(dev_cumsum_i64(bstart.as<int64_t>(), nvec, st));
         int64_t room = 0;
@@ -1447,6 +1475,7 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     // numeric bins use the exact counts, taken before the prefix sum
     GBA_OK(build_bins(nvec, Cp.as<int64_t>(), false, BinLimits{NUM_WAVE_MAX, NUM_BLK1_MAX, NUM_BLK2_MAX}, &P.num));
     if (P.num.count[BIN_GLOBAL] > 0 && P.maxdeg == 0) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
+    if (P.num.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) GBA_OK(narrow_A());
 
     // phases 3/4: Cp = cumsum (cnt)
     GBA_OK(dev_cumsum_i64(Cp.as<int64_t>(), nvec, st));
