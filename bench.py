@@ -105,7 +105,8 @@ def main():
                 tw1 = time.perf_counter()
                 Cc.free(); g.sync()
                 print(f"[bench] rows {lo}:{hi} mxm wall {1e3 * (tw1 - tw):.1f} ms kernel_ms {rep.kernel_ms:.1f} "
-                      f"free {1e3 * (time.perf_counter() - tw1):.1f} ms cnz {rep.cnz}", file=sys.stderr)
+                      f"free {1e3 * (time.perf_counter() - tw1):.1f} ms cnz {rep.cnz} phases "
+                      f"{[round(x, 1) for x in rep.phase_ms[:7]]} bins {list(rep.bin_vectors)}", file=sys.stderr)
             if collect:
                 stats["phase_ms"] += np.array(rep.phase_ms[:])
                 stats["cnz"] += rep.cnz

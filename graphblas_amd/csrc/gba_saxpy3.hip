@@ -272,6 +272,57 @@ bin_stats_kernel(int64_t nlist, const int64_t *__restrict__ list, const int64_t 
     if ((threadIdx.x & 63) == 0) { if (c) atomicAdd(&out[0], c); if (b) atomicAdd(&out[1], b); if (f) atomicAdd(&out[2], f); }
 }
 
+// Persistent workgroups pull vectors from a list; with the heaviest first (longest processing time first)
+// the last vectors to finish are light ones.  Counting sort of the list by floor(log2(work)), descending.
+__global__ void __launch_bounds__(256)
+work_hist_kernel(int64_t n, const int64_t *__restrict__ list, const int64_t *__restrict__ work,
+                 unsigned long long *__restrict__ hist /* [64] */) {
+    __shared__ unsigned int lh[64];
+    if (threadIdx.x < 64) lh[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx < n; idx += stride) {
+        const int64_t w = work[list[idx]];
+        atomicAdd(&lh[w > 0 ? 63 - __builtin_clzll((unsigned long long)w) : 0], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256)
+work_scatter_kernel(int64_t n, const int64_t *__restrict__ list, const int64_t *__restrict__ work,
+                    unsigned long long *__restrict__ cursor /* [64] */, int64_t *__restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx < n; idx += stride) {
+        const int64_t j = list[idx], w = work[j];
+        const int b = w > 0 ? 63 - __builtin_clzll((unsigned long long)w) : 0;
+        out[atomicAdd(&cursor[b], 1ull)] = j;
+    }
+}
+
+static gba_info order_by_work_desc(int64_t n, const int64_t *list, const int64_t *work, DevBuf *out) {
+    hipStream_t st = ctx().stream;
+    GBA_OK(out->alloc((size_t)(n > 0 ? n : 1) * 8));
+    if (n == 0) return GBA_SUCCESS;
+    DevBuf hist; GBA_OK(hist.alloc(64 * 8));
+    GBA_HIP(hipMemsetAsync(hist.p, 0, 64 * 8, st));
+    int64_t blocks = ceil_div(n, 256); if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(work_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, list, work, hist.as<unsigned long long>());
+    unsigned long long h[64], c[64];
+    GBA_HIP(hipMemcpyAsync(h, hist.p, 64 * 8, hipMemcpyDeviceToHost, st));
+    GBA_HIP(hipStreamSynchronize(st));
+    unsigned long long off = 0;
+    for (int b = 63; b >= 0; b--) { c[b] = off; off += h[b]; }
+    GBA_HIP(hipMemcpyAsync(hist.p, c, 64 * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, list, work,
+                       hist.as<unsigned long long>(), out->as<int64_t>());
+    GBA_HIP(hipGetLastError());
+    GBA_HIP(hipStreamSynchronize(st));              // c[] is read by the copy above
+    return GBA_SUCCESS;
+}
+
 // ------------------------------------------------------------- LDS hashing --
 static constexpr int32_t HASH_EMPTY = -1;
 
@@ -1057,6 +1108,55 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
     }
 }
 
+// A unit of work of the numeric panel kernel: the stretches [q0, q1) of C(:,j), where stretch q lies
+// between the recorded boundaries q and q+1 (stretch 0 starts at index 0, the last one is open-ended) and
+// every stretch but the last holds exactly NUM_PANEL_FIT entries -- so the output position of a task is
+// known without any exchange: Cp[j] + q0 * NUM_PANEL_FIT.  Vectors heavier than PANEL_SPLIT_FLOPS are cut
+// into several tasks so that one hub vector cannot keep a single workgroup busy long after the rest finished.
+struct PanelTask { int64_t j; int32_t q0, q1; };
+static constexpr int64_t PANEL_SPLIT_FLOPS = 4000000;
+
+__device__ inline int panel_task_count(int64_t j, const int64_t *__restrict__ Cp, const int64_t *__restrict__ vflops,
+                                       const int64_t *__restrict__ bstart, int64_t *nstretch) {
+    const bool has = bstart && bstart[j + 1] > bstart[j];
+    const int64_t ns = has ? (Cp[j + 1] - Cp[j]) / NUM_PANEL_FIT + 1 : 1;
+    int64_t want = (vflops[j] + PANEL_SPLIT_FLOPS - 1) / PANEL_SPLIT_FLOPS;
+    if (want < 1) want = 1;
+    *nstretch = ns;
+    return (int)((want < ns) ? want : ns);
+}
+
+// count[li] = tasks of the li-th listed vector (count has nlist + 1 entries, the last one zeroed)
+__global__ void __launch_bounds__(256)
+panel_task_count_kernel(int64_t nlist, const int64_t *__restrict__ list, const int64_t *__restrict__ Cp,
+                        const int64_t *__restrict__ vflops, const int64_t *__restrict__ bstart, int64_t *__restrict__ count) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx <= nlist; idx += stride) {
+        int64_t ns;
+        count[idx] = (idx < nlist) ? panel_task_count(list[idx], Cp, vflops, bstart, &ns) : 0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+panel_task_fill_kernel(int64_t nlist, const int64_t *__restrict__ list, const int64_t *__restrict__ Cp,
+                       const int64_t *__restrict__ vflops, const int64_t *__restrict__ bstart,
+                       const int64_t *__restrict__ first_task, PanelTask *__restrict__ tasks) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx < nlist; idx += stride) {
+        const int64_t j = list[idx];
+        int64_t ns;
+        const int nt = panel_task_count(j, Cp, vflops, bstart, &ns);
+        PanelTask *t = tasks + first_task[idx];
+        for (int q = 0; q < nt; q++) {
+            t[q].j = j;
+            t[q].q0 = (int32_t)(ns * q / nt);
+            t[q].q1 = (int32_t)(ns * (q + 1) / nt);
+        }
+    }
+}
+
 // Multiplicative (Fibonacci) hash into NUM_PANEL_SLOTS = 2^13 slots.  The order in which a panel's
 // entries leave the table is free (C is returned jumbled), so the function need not be GB_HASHF.
 __device__ inline uint32_t panel_hash(int32_t key) { return ((uint32_t)key * 0x9E3779B1u) >> 19; }
@@ -1064,7 +1164,7 @@ static_assert(NUM_PANEL_SLOTS == (1 << 13), "panel_hash keeps the top 13 bits");
 
 template <class S>
 __global__ void __launch_bounds__(PANEL_THREADS)
-num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int64_t cvlen,
+num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpView A, SpView B, MaskView M, int64_t cvlen,
                  int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
                  const int64_t *__restrict__ Cp, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx,
                  const int64_t *__restrict__ bstart, const int64_t *__restrict__ bounds) {
@@ -1087,11 +1187,12 @@ num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
         __syncthreads();
         const int64_t li = row;
         if (li >= nlist) break;
-        const int64_t j = list[li];
+        const PanelTask task = tasks[li];
+        const int64_t j = task.j;
         const int64_t pB0 = B.p[j], deg = B.p[j + 1] - pB0;
         int64_t pC = Cp[j];
         const int64_t cj = Cp[j + 1] - pC;
-        int64_t base = 0;
+        int64_t base = 0, iend = PANEL_INF;
         int64_t width = (cj > 0) ? (cvlen * NUM_PANEL_TARGET) / cj : cvlen;
         if (width > 4096) width = 4096;                 // the low indices are the dense end of a power-law vector
         if (width < 1) width = 1;
@@ -1099,7 +1200,12 @@ num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
         // boundaries recorded by the symbolic sweep, if it was the panel kernel that counted this vector
         const int64_t *jb = nullptr;
         int64_t nb = 0, mb = 0;
-        if (bstart && bstart[j + 1] > bstart[j]) { jb = bounds + bstart[j]; nb = cj / NUM_PANEL_FIT; }
+        if (bstart && bstart[j + 1] > bstart[j]) {
+            jb = bounds + bstart[j]; nb = cj / NUM_PANEL_FIT;
+            if (task.q0 > 0) { base = jb[task.q0 - 1]; pC += (int64_t)task.q0 * NUM_PANEL_FIT; mb = task.q0; }
+            if (task.q1 <= nb) iend = jb[task.q1 - 1];
+        }
+        const int64_t ibeg = base;
         int64_t shrink = 0;                             // halvings after an overflow (never needed with boundaries)
         while (true) {
             if (jb) {
@@ -1110,11 +1216,12 @@ num_panel_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
             }
             // a panel no wider than the table needs no hashing: slot = i - base, any number of entries fits
             const bool direct = width <= NUM_PANEL_SLOTS;
-            const int64_t lim = base + (direct ? NUM_PANEL_SLOTS : ((width < PANEL_MAX_WIDTH) ? width : PANEL_MAX_WIDTH));
+            int64_t lim = base + (direct ? NUM_PANEL_SLOTS : ((width < PANEL_MAX_WIDTH) ? width : PANEL_MAX_WIDTH));
+            if (lim > iend) lim = iend;
             const int64_t pend = (lim >= cvlen) ? PANEL_INF : lim;
             if (threadIdx.x == 0) { Q.overflow = 0; Q.more = 0; out_cursor = 0; }
             __syncthreads();
-            panel_walk<NUM_PANEL_UNROLL>(A, B, pB0, deg, 0, pend, PANEL_INF, first, pc, &Q,
+            panel_walk<NUM_PANEL_UNROLL>(A, B, pB0, deg, ibeg, pend, iend, first, pc, &Q,
                 [&](int32_t i, int64_t pA, int64_t pB) -> Z {
                     return product(sr, A, B, apat, bpat, i, B.i[pB], j, pA, pB);
                 },
@@ -1291,6 +1398,23 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
     if (nb.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) {
         int64_t nblocks = (int64_t)ctx().num_cu;
         if (nblocks > nb.count[BIN_GLOBAL]) nblocks = nb.count[BIN_GLOBAL];
+        // tasks: heaviest first, hub vectors cut at recorded boundaries
+        const int64_t nl = nb.count[BIN_GLOBAL];
+        DevBuf order, tcount, tasks;
+        GBA_OK(order_by_work_desc(nl, nb.list(BIN_GLOBAL), P.vflops, &order));
+        GBA_OK(tcount.alloc((size_t)(nl + 1) * 8));
+        int64_t tb = ceil_div(nl + 1, 256); if (tb > 4096) tb = 4096;
+        hipLaunchKernelGGL(panel_task_count_kernel, dim3((unsigned)tb), dim3(256), 0, st, nl, order.as<int64_t>(), P.Cp,
+                           P.vflops, P.bstart, tcount.as<int64_t>());
+        GBA_HIP(hipGetLastError());
+        GBA_OK(dev_cumsum_i64(tcount.as<int64_t>(), nl, st));
+        int64_t ntasks = 0;
+        GBA_OK(dev_read_i64(tcount.as<int64_t>() + nl, &ntasks));
+        GBA_OK(tasks.alloc((size_t)(ntasks > 0 ? ntasks : 1) * sizeof(PanelTask)));
+        hipLaunchKernelGGL(panel_task_fill_kernel, dim3((unsigned)tb), dim3(256), 0, st, nl, order.as<int64_t>(), P.Cp,
+                           P.vflops, P.bstart, tcount.as<int64_t>(), tasks.as<PanelTask>());
+        GBA_HIP(hipGetLastError());
+        if (nblocks > ntasks) nblocks = ntasks;
         DevBuf scratch, next;
         GBA_OK(scratch.alloc((size_t)nblocks * PANEL_SCRATCH_ARRAYS * (size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
         GBA_OK(next.alloc(24));
@@ -1299,7 +1423,7 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         const size_t lds = (size_t)NUM_PANEL_SLOTS * (sizeof(ACC) + 4);
         GBA_OK(set_lds(k, lds));
         hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
-                           sr, nb.count[BIN_GLOBAL], nb.list(BIN_GLOBAL), P.A, P.B, P.M, P.cvlen, P.maxdeg,
+                           sr, ntasks, tasks.as<PanelTask>(), P.A, P.B, P.M, P.cvlen, P.maxdeg,
                            scratch.as<int64_t>(), next.as<unsigned long long>(), P.Cp, P.Ci, Cx, P.bstart, P.bounds);
         GBA_HIP(hipGetLastError());
         mark(4);
@@ -1373,8 +1497,10 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
         GBA_HIP(hipMemsetAsync(next.p, 0, 8, st));
         const size_t lds = (size_t)SYM_PANEL_WORDS * 4;
         GBA_OK(set_lds(sym_panel_kernel, lds));
+        DevBuf order;
+        GBA_OK(order_by_work_desc(sb.count[BIN_GLOBAL], sb.list(BIN_GLOBAL), P.vflops, &order));
         hipLaunchKernelGGL(sym_panel_kernel, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
-                           sb.count[BIN_GLOBAL], sb.list(BIN_GLOBAL), P.A, P.B, P.M, P.cvlen, P.maxdeg,
+                           sb.count[BIN_GLOBAL], order.as<int64_t>(), P.A, P.B, P.M, P.cvlen, P.maxdeg,
                            scratch.as<int64_t>(), next.as<unsigned long long>(), cnt, P.bstart, P.bounds);
         GBA_HIP(hipGetLastError());
         GBA_HIP(hipStreamSynchronize(st));

@@ -85,6 +85,22 @@ def test_several_symbolic_panels(gba):
     assert_same(got, want, exact=True)
 
 
+@pytest.mark.parametrize("sr", ["PLUS_TIMES_FP64", "MIN_FIRSTJ_INT64"])
+def test_hub_vectors_are_cut_into_several_tasks(gba, sr):
+    """Vectors of > 4e6 multiply-adds are split at recorded boundaries and emitted by several
+    workgroups, each at its own offset inside C(:,j)."""
+    t = Type.FP64 if sr.endswith("FP64") else Type.INT64
+    As, Bs = _heavy_pair(400_000, 2, 3000, 48, 220_000, 1, seed=11)
+    A, B = _mat(As, t), _mat(Bs, t)
+    dA, dB = A.to_device(), B.to_device()
+    mw, fl = gba.AxB_saxpy3_flopcount(None, False, dA, dB)
+    dA.free(); dB.free()
+    assert np.diff(fl).max() > 2 * 4_000_000
+    got, rep = _run(gba, A, B, sr)
+    want = oracle.saxpy3(None, False, False, A, B, sr)
+    assert_same(got, want, exact=True, what=sr)
+
+
 @pytest.mark.parametrize("sr,t", [
     ("PLUS_TIMES_INT8", Type.INT8), ("PLUS_TIMES_UINT16", Type.UINT16), ("PLUS_TIMES_FP32", Type.FP32),
     ("MIN_PLUS_FP64", Type.FP64), ("MAX_MIN_INT32", Type.INT32), ("LOR_LAND_BOOL", Type.BOOL),
