@@ -46,8 +46,15 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("GBA_BENCH_REHEARSE"):
+            # rehearsal of the N > 1 code path on a box with one GPU: every rank on device 0, gloo
+            # instead of RCCL (RCCL refuses two ranks on one device).  Not a measurement.
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import graphblas_amd as g
     from graphblas_amd import gen, Type, DeviceMatrix
     from graphblas_amd.dist import row_flops, split_by_flops, chunks_by_flops, RowBlockExchange

@@ -1114,13 +1114,21 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
 // known without any exchange: Cp[j] + q0 * NUM_PANEL_FIT.  Vectors heavier than PANEL_SPLIT_FLOPS are cut
 // into several tasks so that one hub vector cannot keep a single workgroup busy long after the rest finished.
 struct PanelTask { int64_t j; int32_t q0, q1; };
-static constexpr int64_t PANEL_SPLIT_FLOPS = 4000000;
+static constexpr int64_t PANEL_SPLIT_FLOPS = 4000000;          // default; GBA_PANEL_SPLIT_FLOPS overrides (tuning)
+static int64_t panel_split_flops() {
+    static const int64_t v = [] {
+        const char *e = getenv("GBA_PANEL_SPLIT_FLOPS");
+        const long long x = e ? atoll(e) : 0;
+        return (int64_t)(x > 0 ? x : PANEL_SPLIT_FLOPS);
+    }();
+    return v;
+}
 
 __device__ inline int panel_task_count(int64_t j, const int64_t *__restrict__ Cp, const int64_t *__restrict__ vflops,
-                                       const int64_t *__restrict__ bstart, int64_t *nstretch) {
+                                       const int64_t *__restrict__ bstart, int64_t split, int64_t *nstretch) {
     const bool has = bstart && bstart[j + 1] > bstart[j];
     const int64_t ns = has ? (Cp[j + 1] - Cp[j]) / NUM_PANEL_FIT + 1 : 1;
-    int64_t want = (vflops[j] + PANEL_SPLIT_FLOPS - 1) / PANEL_SPLIT_FLOPS;
+    int64_t want = (vflops[j] + split - 1) / split;
     if (want < 1) want = 1;
     *nstretch = ns;
     return (int)((want < ns) ? want : ns);
@@ -1129,25 +1137,26 @@ __device__ inline int panel_task_count(int64_t j, const int64_t *__restrict__ Cp
 // count[li] = tasks of the li-th listed vector (count has nlist + 1 entries, the last one zeroed)
 __global__ void __launch_bounds__(256)
 panel_task_count_kernel(int64_t nlist, const int64_t *__restrict__ list, const int64_t *__restrict__ Cp,
-                        const int64_t *__restrict__ vflops, const int64_t *__restrict__ bstart, int64_t *__restrict__ count) {
+                        const int64_t *__restrict__ vflops, const int64_t *__restrict__ bstart, int64_t split,
+                        int64_t *__restrict__ count) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; idx <= nlist; idx += stride) {
         int64_t ns;
-        count[idx] = (idx < nlist) ? panel_task_count(list[idx], Cp, vflops, bstart, &ns) : 0;
+        count[idx] = (idx < nlist) ? panel_task_count(list[idx], Cp, vflops, bstart, split, &ns) : 0;
     }
 }
 
 __global__ void __launch_bounds__(256)
 panel_task_fill_kernel(int64_t nlist, const int64_t *__restrict__ list, const int64_t *__restrict__ Cp,
-                       const int64_t *__restrict__ vflops, const int64_t *__restrict__ bstart,
+                       const int64_t *__restrict__ vflops, const int64_t *__restrict__ bstart, int64_t split,
                        const int64_t *__restrict__ first_task, PanelTask *__restrict__ tasks) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; idx < nlist; idx += stride) {
         const int64_t j = list[idx];
         int64_t ns;
-        const int nt = panel_task_count(j, Cp, vflops, bstart, &ns);
+        const int nt = panel_task_count(j, Cp, vflops, bstart, split, &ns);
         PanelTask *t = tasks + first_task[idx];
         for (int q = 0; q < nt; q++) {
             t[q].j = j;
@@ -1405,14 +1414,14 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         GBA_OK(tcount.alloc((size_t)(nl + 1) * 8));
         int64_t tb = ceil_div(nl + 1, 256); if (tb > 4096) tb = 4096;
         hipLaunchKernelGGL(panel_task_count_kernel, dim3((unsigned)tb), dim3(256), 0, st, nl, order.as<int64_t>(), P.Cp,
-                           P.vflops, P.bstart, tcount.as<int64_t>());
+                           P.vflops, P.bstart, panel_split_flops(), tcount.as<int64_t>());
         GBA_HIP(hipGetLastError());
         GBA_OK(dev_cumsum_i64(tcount.as<int64_t>(), nl, st));
         int64_t ntasks = 0;
         GBA_OK(dev_read_i64(tcount.as<int64_t>() + nl, &ntasks));
         GBA_OK(tasks.alloc((size_t)(ntasks > 0 ? ntasks : 1) * sizeof(PanelTask)));
         hipLaunchKernelGGL(panel_task_fill_kernel, dim3((unsigned)tb), dim3(256), 0, st, nl, order.as<int64_t>(), P.Cp,
-                           P.vflops, P.bstart, tcount.as<int64_t>(), tasks.as<PanelTask>());
+                           P.vflops, P.bstart, panel_split_flops(), tcount.as<int64_t>(), tasks.as<PanelTask>());
         GBA_HIP(hipGetLastError());
         if (nblocks > ntasks) nblocks = ntasks;
         DevBuf scratch, next;
