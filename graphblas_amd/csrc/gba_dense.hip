@@ -213,10 +213,10 @@ dot_tile_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64
         const int idx = it * DOT_TILE_THREADS + tid;
         const int64_t p = start + idx;
         if (p < end) {
-            const int64_t k = Ai[p];
+            const int64_t k = __builtin_nontemporal_load(&Ai[p]);   // streamed once: keep the cache for B
             const bool ok = !B.b || B.b[boff + k];
             Z t = Z();
-            if (ok) t = sr.mult(load_x<X>(Ax, p, A_iso, apat), load_x<X>(Bx, boff + k, B.iso, bpat), 0, k, j);
+            if (ok) t = sr.mult(((apat) ? X() : __builtin_nontemporal_load(&Ax[A_iso ? 0 : p])), load_x<X>(Bx, boff + k, B.iso, bpat), 0, k, j);
             prod[idx] = t;
             have[idx] = ok;
         }
