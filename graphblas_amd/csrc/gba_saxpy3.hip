@@ -718,7 +718,7 @@ static constexpr int PANEL_NPT = 2;                                   // neighbo
 static constexpr int PANEL_STEP = PANEL_THREADS * PANEL_NPT;
 static constexpr int PANEL_SEGCAP = 4 * PANEL_THREADS;                // runs queued in LDS before they are expanded
 static constexpr int PANEL_UNROLL_MAX = 8;
-static constexpr int SYM_PANEL_UNROLL = 4, NUM_PANEL_UNROLL = 4;            // products in flight per thread
+static constexpr int SYM_PANEL_UNROLL = 2, NUM_PANEL_UNROLL = 2;            // products in flight per thread
 static constexpr int PANEL_T_BITS = 24;
 static constexpr int64_t PANEL_MAX_DEG = (int64_t)1 << PANEL_T_BITS;
 static constexpr int64_t PANEL_MAX_WIDTH = (int64_t)1 << 20;          // (SEGCAP-1) runs of this length stay below 2^32
@@ -1065,14 +1065,9 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                     }
                 });
             // count in index order: each thread owns SYM_WORDS_PER_THREAD consecutive words
-            uint32_t x[SYM_WORDS_PER_THREAD];
             int mine = 0;
             const int w0 = tid * SYM_WORDS_PER_THREAD;
-#pragma unroll
-            for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) {
-                x[q] = bm[w0 + q];
-                if (x[q]) { mine += __builtin_popcount(x[q]); bm[w0 + q] = 0; }
-            }
+            for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) mine += __builtin_popcount(bm[w0 + q]);
             int incl = mine;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
@@ -1085,19 +1080,20 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
             const int64_t m = lo / NUM_PANEL_FIT + 1;       // the next multiple to be crossed
             if (m * NUM_PANEL_FIT <= lo + mine) {
                 int r = (int)(m * NUM_PANEL_FIT - lo);      // the r-th set bit of the slice, 1-based
-#pragma unroll
-                for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) {
-                    const int pcq = __builtin_popcount(x[q]);
-                    if (r > 0 && r <= pcq) {
-                        uint32_t y = x[q];
+                for (int q = 0; q < SYM_WORDS_PER_THREAD && r > 0; q++) {
+                    const uint32_t xq = bm[w0 + q];
+                    const int pcq = __builtin_popcount(xq);
+                    if (r <= pcq) {
+                        uint32_t y = xq;
                         for (int z = 1; z < r; z++) y &= y - 1;
                         jb[m - 1] = base + (int64_t)(w0 + q) * 32 + __builtin_ctz(y) + 1;
                         r = 0;
-                    } else if (r > 0) {
+                    } else {
                         r -= pcq;
                     }
                 }
             }
+            if (mine) for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) bm[w0 + q] = 0;   // own slice only: no barrier needed
             seen += total;
             const int more = Q.more;
             pc.swap();
