@@ -13,8 +13,8 @@
 //   * rowscale/colscale are detected and reported, then run through the saxpy
 //     kernels (each C entry is a single product, so the values are identical);
 //   * the write-back C<M> = accum(C,T) (Source/GB_accum_mask.c) exists on the
-//     device for the transplant case and for bitmap/full C; a sparse C that
-//     needs a merge with T is declined with GBA_NOT_IMPLEMENTED.
+//     device: transplant, bitmap/full C (one thread per position), sparse C
+//     merged with a sparse T (one wavefront per vector).
 #include "gba_internal.hpp"
 #include <cmath>
 
@@ -378,6 +378,157 @@ static gba_info writeback_dense(const Call &k, const gba_matrix *M, gba_matrix *
     return GBA_SUCCESS;
 }
 
+static void free_unaliased(gba_matrix *C, const Call &k);
+
+// ------------------------------------------------------ sparse write-back --
+// C<M> = accum (C,T) with C and T both sparse, sorted and free of zombies: what GB_accum_mask
+// (Source/GB_accum_mask.c:14-60) builds from GB_add and GB_mask.  One wavefront per vector.  The
+// surviving entries of C(:,j) are emitted first, then the entries of T(:,j) that have no partner in
+// C(:,j); partners are found by bisection of the other (sorted) list.  The result is returned
+// jumbled, as the library allows for any sparse matrix (Source/GB_mxm.c:158-162).
+__device__ inline int64_t find_index(const int64_t *__restrict__ X, int64_t lo, int64_t hi, int64_t i) {
+    hi--;
+    while (lo <= hi) {
+        const int64_t mid = (lo + hi) >> 1, v = X[mid];
+        if (v < i) lo = mid + 1; else if (v > i) hi = mid - 1; else return mid;
+    }
+    return -1;
+}
+
+template <class Z, bool FILL>
+__global__ void __launch_bounds__(256)
+writeback_sparse_kernel(int64_t nvec, const int64_t *__restrict__ Cp, const int64_t *__restrict__ Ci,
+                        const Z *__restrict__ Cx, const int64_t *__restrict__ Tp, const int64_t *__restrict__ Ti,
+                        const Z *__restrict__ Tx, bool T_iso, WbMask M, int accum_op, bool C_replace,
+                        int64_t *__restrict__ Rp, int64_t *__restrict__ Ri, Z *__restrict__ Rx) {
+    const int lane = threadIdx.x & 63;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; j < nvec; j += stride) {
+        const int64_t c0 = Cp[j], c1 = Cp[j + 1], t0 = Tp[j], t1 = Tp[j + 1];
+        int64_t out = FILL ? Rp[j] : 0;
+        for (int64_t q = c0; q < c1; q += 64) {                 // entries of C(:,j)
+            const int64_t p = q + lane;
+            bool keep = false; int64_t i = 0; Z z = Z();
+            if (p < c1) {
+                i = Ci[p];
+                const int64_t pt = find_index(Ti, t0, t1, i);
+                if (wb_mask(M, i, j)) {
+                    if (pt >= 0) {
+                        const Z t = Tx[T_iso ? 0 : pt];
+                        z = (accum_op != GBA_NOP) ? mult_tt<Z>(accum_op, Cx[p], t) : t;
+                        keep = true;
+                    } else if (accum_op != GBA_NOP) {
+                        z = Cx[p]; keep = true;                  // Z(i,j) = C(i,j)
+                    }                                           // no accum: Z = T has no entry here
+                } else if (!C_replace) {
+                    z = Cx[p]; keep = true;
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            if (FILL && keep) {
+                const int64_t r = out + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                Ri[r] = i; Rx[r] = z;
+            }
+            out += __builtin_popcountll(m);
+        }
+        for (int64_t q = t0; q < t1; q += 64) {                 // entries of T(:,j) without a partner
+            const int64_t p = q + lane;
+            bool keep = false; int64_t i = 0;
+            if (p < t1) {
+                i = Ti[p];
+                keep = find_index(Ci, c0, c1, i) < 0 && wb_mask(M, i, j);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (FILL && keep) {
+                const int64_t r = out + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                Ri[r] = i; Rx[r] = Tx[T_iso ? 0 : p];
+            }
+            out += __builtin_popcountll(m);
+        }
+        if (!FILL && lane == 0) Rp[j] = out;
+    }
+}
+
+static gba_info writeback_sparse(const Call &k, const gba_matrix *M, gba_matrix *T) {
+    gba_matrix *C = k.C;
+    hipStream_t st = ctx().stream;
+    if (T->vlen != C->vlen || T->vdim != C->vdim) GBA_FAIL(GBA_PANIC, "write-back: T is %ld-by-%ld, C is %ld-by-%ld",
+                                                           (long)T->vlen, (long)T->vdim, (long)C->vlen, (long)C->vdim);
+    if (T->type != C->type) GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back with typecast (%d -> %d)", T->type, C->type);
+    if (k.has_accum && (k.accum.type != C->type || !accum_op_ok(k.accum.op)))
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "accum operator %d on type %d", k.accum.op, k.accum.type);
+    if (C->iso) GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back into an iso-valued C");
+    if (C->jumbled || C->nzombies) GBA_OK(matrix_wait(C));
+    if (T->jumbled || T->nzombies) GBA_OK(matrix_wait(T));
+    const int64_t nvec = C->vdim;
+    WbMask wm; GBA_OK(make_wb_mask(M, k.Mask_comp, k.Mask_struct, &wm));
+    DevBuf Rp, Ri, Rx;
+    GBA_OK(Rp.alloc((size_t)(nvec + 1) * 8));
+    GBA_HIP(hipMemsetAsync(Rp.p, 0, (size_t)(nvec + 1) * 8, st));
+    const int acc = k.has_accum ? k.accum.op : (int)GBA_NOP;
+    int64_t blocks = ceil_div(nvec * 64, 256); if (blocks > 16384) blocks = 16384; if (blocks < 1) blocks = 1;
+    int64_t rnz = 0;
+    GBA_OK(with_type(C->type, [&](auto z) -> gba_info {
+        using Z = decltype(z);
+        if (nvec > 0) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(writeback_sparse_kernel<Z, false>), dim3((unsigned)blocks), dim3(256), 0, st,
+                               nvec, C->p, C->i, reinterpret_cast<const Z *>(C->x), T->p, T->i, reinterpret_cast<const Z *>(T->x),
+                               T->iso, wm, acc, k.C_replace, Rp.as<int64_t>(), (int64_t *)nullptr, (Z *)nullptr);
+            GBA_HIP(hipGetLastError());
+        }
+        GBA_OK(dev_cumsum_i64(Rp.as<int64_t>(), nvec, st));
+        GBA_OK(dev_read_i64(Rp.as<int64_t>() + nvec, &rnz));
+        GBA_OK(Ri.alloc((size_t)(rnz > 0 ? rnz : 1) * 8));
+        GBA_OK(Rx.alloc((size_t)(rnz > 0 ? rnz : 1) * sizeof(Z)));
+        if (nvec > 0 && rnz > 0) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(writeback_sparse_kernel<Z, true>), dim3((unsigned)blocks), dim3(256), 0, st,
+                               nvec, C->p, C->i, reinterpret_cast<const Z *>(C->x), T->p, T->i, reinterpret_cast<const Z *>(T->x),
+                               T->iso, wm, acc, k.C_replace, Rp.as<int64_t>(), Ri.as<int64_t>(), Rx.as<Z>());
+            GBA_HIP(hipGetLastError());
+        }
+        return GBA_SUCCESS;
+    }));
+    GBA_HIP(hipStreamSynchronize(st));
+    free_unaliased(C, k);
+    C->p = reinterpret_cast<int64_t *>(Rp.release());
+    C->i = reinterpret_cast<int64_t *>(Ri.release());
+    C->x = Rx.release();
+    C->nvec = nvec; C->nvals = rnz; C->nzombies = 0; C->jumbled = true; C->iso = false; C->sparsity = GBA_SPARSE;
+    return GBA_SUCCESS;
+}
+
+// a sparse C meets a bitmap/full T (e.g. w += A*u with a sparse w): C becomes bitmap first
+static gba_info sparse_C_to_bitmap(gba_matrix *C, const Call &k) {
+    hipStream_t st = ctx().stream;
+    const int64_t n = C->vlen * C->vdim;
+    if (C->vlen > 0 && n / C->vlen != C->vdim) GBA_FAIL(GBA_NOT_IMPLEMENTED, "bitmap form of C overflows");
+    if (C->iso) GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back into an iso-valued C");
+    if (C->nzombies) GBA_OK(matrix_wait(C));
+    const size_t zs = type_size(C->type);
+    DevBuf Db, Dx;
+    GBA_OK(Db.alloc((size_t)(n > 0 ? n : 1)));
+    GBA_OK(Dx.alloc((size_t)(n > 0 ? n : 1) * zs));
+    GBA_HIP(hipMemsetAsync(Db.p, 0, (size_t)(n > 0 ? n : 1), st));
+    if (C->nvals > 0) {
+        GBA_OK(with_type(C->type, [&](auto z) -> gba_info {
+            using Z = decltype(z);
+            int64_t blocks = ceil_div(C->nvec * 64, 256); if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(scatter_sparse_kernel<Z>), dim3((unsigned)blocks), dim3(256), 0, st,
+                               C->nvec, C->p, C->i, reinterpret_cast<const Z *>(C->x), false, C->vlen, Dx.as<Z>(), Db.as<int8_t>());
+            GBA_HIP(hipGetLastError());
+            return GBA_SUCCESS;
+        }));
+    }
+    GBA_HIP(hipStreamSynchronize(st));
+    const int64_t nvals = C->nvals;
+    free_unaliased(C, k);
+    C->b = reinterpret_cast<int8_t *>(Db.release());
+    C->x = Dx.release();
+    C->sparsity = GBA_BITMAP; C->nvec = C->vdim; C->nvals = nvals; C->jumbled = false;
+    return GBA_SUCCESS;
+}
+
 static void free_unaliased(gba_matrix *C, const Call &k) {
     auto aliased = [&](const void *q) {
         if (!q) return true;
@@ -703,8 +854,19 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
         gba_matrix_free_content(&T);
         return info;
     }
+    if (is_sparse(C) && is_sparse(&T)) {
+        info = writeback_sparse(k, M, &T);
+        gba_matrix_free_content(&T);
+        return info;
+    }
+    if (is_sparse(C) && is_dense_fmt(&T)) {
+        info = sparse_C_to_bitmap(C, k);
+        if (info == GBA_SUCCESS) info = writeback_dense(k, M, &T);
+        gba_matrix_free_content(&T);
+        return info;
+    }
     gba_matrix_free_content(&T);
-    GBA_FAIL(GBA_NOT_IMPLEMENTED, "C<M> = accum (C,T) into a sparse C that already holds entries");
+    GBA_FAIL(GBA_NOT_IMPLEMENTED, "C<M> = accum (C,T) with C of sparsity %d and T of sparsity %d", C->sparsity, T.sparsity);
 }
 
 }  // namespace gba

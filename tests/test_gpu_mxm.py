@@ -58,6 +58,55 @@ def test_mxm_masked_into_empty_C(gba, desc, mkind):
     assert rep.mask_applied
 
 
+@pytest.mark.parametrize("desc", ["", "R", "S", "RS", "SC", "RSC", "C", "T0", "ST1"])
+@pytest.mark.parametrize("accum", [None, "PLUS_FP64", "MIN_FP64", "SECOND_FP64"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_mxm_into_a_sparse_C_that_holds_entries(gba, desc, accum, masked):
+    """C<M> = accum (C, A*B) with a sparse, non-empty C: the write-back of GB_accum_mask
+    (Source/GB_accum_mask.c), every combination of accum / mask / complement / replace."""
+    if not masked and any(ch in desc for ch in "SC"):
+        pytest.skip("mask modifiers without a mask")
+    n = 70
+    A, B = _rand(n, n, 0.08, 21), _rand(n, n, 0.08, 22)
+    C0 = _rand(n, n, 0.15, 23)
+    M = _rand(n, n, 0.3, 24, t=Type.INT8, lo=0, hi=2) if masked else None
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    dM = M.to_device() if masked else None
+    gba.mxm(dC, dM, accum, "PLUS_TIMES_FP64", dA, dB, desc)
+    p, v = oracle.mxm_spec(C0, M, accum, "PLUS_TIMES_FP64", A, B, desc)
+    assert_dense_same(dC.to_host(), p, v, exact=True, what=f"{desc}/{accum}/{masked}")
+
+
+def test_accumulating_over_iterations_keeps_C_consistent(gba):
+    """C += A*B three times in a row (C jumbled after each round is waited on by the next)."""
+    n = 120
+    A, B = _rand(n, n, 0.05, 31), _rand(n, n, 0.05, 32)
+    C0 = _rand(n, n, 0.02, 33)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    S = C0.to_scipy().toarray()
+    P = A.to_scipy().toarray() @ B.to_scipy().toarray()
+    for _ in range(3):
+        gba.mxm(dC, None, "PLUS_FP64", "PLUS_TIMES_FP64", dA, dB, None)
+        S = S + P
+    got = dC.to_host()
+    assert np.array_equal(got.to_scipy().toarray(), S)
+    assert got.nvals == np.count_nonzero((C0.to_scipy().toarray() != 0) | (P != 0))
+
+
+def test_mxv_into_a_sparse_vector_with_entries(gba):
+    """w += A*u with a sparse w and a full u: T is bitmap, so w is made bitmap for the update."""
+    n = 200
+    A = _rand(n, n, 0.04, 41, t=Type.FP32)
+    rng = np.random.default_rng(42)
+    u = Matrix.full_vector(rng.integers(1, 5, n).astype(np.float32))
+    idx = rng.choice(n, 20, replace=False)
+    w0 = Matrix.sparse_vector(n, idx, rng.integers(1, 5, 20).astype(np.float32))
+    dA, du, dw = A.to_device(), u.to_device(), w0.to_device()
+    gba.mxv(dw, None, "PLUS_FP32", "PLUS_TIMES_FP32", dA, du, None)
+    p, v = oracle.mxm_spec(w0, None, "PLUS_FP32", "PLUS_TIMES_FP32", A, u, "")
+    assert_dense_same(dw.to_host(), p, v, exact=True)
+
+
 def test_mxm_triangle_count_call(gba):
     """C<L,struct> = L*L' exactly as LAGraph issues it: GrB_mxm(C, L, NULL, PLUS_PAIR_INT64, L, L, GrB_DESC_ST1)."""
     G = gen.rmat(9, 16, seed=42, symmetric=True, drop_diagonal=True, values="ones", type=Type.INT64)
