@@ -3,7 +3,9 @@
 //   transpose     AT = A', bucket method             (Source/GB_transpose_bucket.c, GB_transpose_cast.c:1-38)
 //   partition     flop-balanced 1-D split            (Source/GB_pslice.c:116)
 #include "gba_internal.hpp"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <vector>
 
 namespace gba {
 
@@ -138,6 +140,94 @@ classify_sort_kernel(int64_t nvec, const int64_t *__restrict__ Cp, const int64_t
     }
 }
 
+// Vectors longer than the LDS sort (saxpy3 emits heavy vectors panel by panel, each panel in table
+// order): segmented radix sort of (index, position) pairs on compact copies, a bounded number of
+// entries per batch, then the values follow their positions.
+__global__ void __launch_bounds__(256)
+long_len_kernel(int64_t n, const int64_t *__restrict__ list, const int64_t *__restrict__ Cp, int64_t *__restrict__ len) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q <= n) len[q] = (q < n) ? Cp[list[q] + 1] - Cp[list[q]] : 0;
+}
+
+__global__ void __launch_bounds__(256)
+long_gather_kernel(int64_t q0, const int64_t *__restrict__ list, const int64_t *__restrict__ Cp,
+                   const int64_t *__restrict__ cbeg, const int64_t *__restrict__ Ci,
+                   int64_t *__restrict__ keys, int64_t *__restrict__ pos, int64_t *__restrict__ seg) {
+    const int64_t q = q0 + blockIdx.x;
+    const int64_t base = cbeg[q0], c0 = cbeg[q] - base, p0 = Cp[list[q]], n = cbeg[q + 1] - cbeg[q];
+    if (threadIdx.x == 0) { seg[blockIdx.x] = c0; if (blockIdx.x == gridDim.x - 1) seg[gridDim.x] = c0 + n; }
+    for (int64_t t = threadIdx.x; t < n; t += blockDim.x) { keys[c0 + t] = Ci[p0 + t]; pos[c0 + t] = p0 + t; }
+}
+
+__global__ void __launch_bounds__(256)
+long_values_kernel(int64_t total, const int64_t *__restrict__ pos, const uint8_t *__restrict__ Cx, int esize,
+                   uint8_t *__restrict__ vals) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < total; c += stride) {
+        const int64_t src = pos[c];
+        for (int b = 0; b < esize; b++) vals[c * esize + b] = Cx[src * esize + b];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+long_scatter_kernel(int64_t q0, const int64_t *__restrict__ list, const int64_t *__restrict__ Cp,
+                    const int64_t *__restrict__ cbeg, const int64_t *__restrict__ keys,
+                    const uint8_t *__restrict__ vals, int esize, int64_t *__restrict__ Ci, uint8_t *__restrict__ Cx) {
+    const int64_t q = q0 + blockIdx.x;
+    const int64_t c0 = cbeg[q] - cbeg[q0], p0 = Cp[list[q]], n = cbeg[q + 1] - cbeg[q];
+    for (int64_t t = threadIdx.x; t < n; t += blockDim.x) {
+        Ci[p0 + t] = keys[c0 + t];
+        for (int b = 0; b < esize; b++) Cx[(p0 + t) * esize + b] = vals[(c0 + t) * esize + b];
+    }
+}
+
+static gba_info sort_long_vectors(gba_matrix *C, const int64_t *list, int64_t n, int esize) {
+    hipStream_t st = ctx().stream;
+    DevBuf cbeg;
+    GBA_OK(cbeg.alloc((size_t)(n + 1) * 8));
+    hipLaunchKernelGGL(long_len_kernel, dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st, n, list, C->p, cbeg.as<int64_t>());
+    GBA_HIP(hipGetLastError());
+    GBA_OK(dev_cumsum_i64(cbeg.as<int64_t>(), n, st));
+    std::vector<int64_t> hb((size_t)n + 1);
+    GBA_HIP(hipMemcpyAsync(hb.data(), cbeg.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, st));
+    GBA_HIP(hipStreamSynchronize(st));
+    const int64_t budget = (int64_t)1 << 27;            // entries per batch (the sort takes 32-bit counts)
+    int end_bit = 1;
+    while (end_bit < 63 && ((int64_t)1 << end_bit) < C->vlen) end_bit++;
+    for (int64_t q0 = 0; q0 < n;) {
+        int64_t q1 = q0 + 1;
+        while (q1 < n && hb[(size_t)q1 + 1] - hb[(size_t)q0] <= budget && q1 - q0 < 65535 * 16) q1++;
+        const int64_t total = hb[(size_t)q1] - hb[(size_t)q0], nseg = q1 - q0;
+        if (total >= ((int64_t)1 << 31)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "vector of %ld entries is too long for the device sort", (long)total);
+        DevBuf keys, keys2, pos, pos2, vals, seg, tmp;
+        GBA_OK(keys.alloc((size_t)total * 8)); GBA_OK(keys2.alloc((size_t)total * 8));
+        GBA_OK(pos.alloc((size_t)total * 8));  GBA_OK(pos2.alloc((size_t)total * 8));
+        GBA_OK(vals.alloc((size_t)total * esize));
+        GBA_OK(seg.alloc((size_t)(nseg + 1) * 8));
+        hipLaunchKernelGGL(long_gather_kernel, dim3((unsigned)nseg), dim3(256), 0, st, q0, list, C->p, cbeg.as<int64_t>(), C->i,
+                           keys.as<int64_t>(), pos.as<int64_t>(), seg.as<int64_t>());
+        GBA_HIP(hipGetLastError());
+        size_t bytes = 0;
+        GBA_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, keys.as<int64_t>(), keys2.as<int64_t>(),
+                                                            pos.as<int64_t>(), pos2.as<int64_t>(), (int)total, (int)nseg,
+                                                            seg.as<int64_t>(), seg.as<int64_t>() + 1, 0, end_bit, st));
+        GBA_OK(tmp.alloc(bytes ? bytes : 1));
+        GBA_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp.p, bytes, keys.as<int64_t>(), keys2.as<int64_t>(),
+                                                            pos.as<int64_t>(), pos2.as<int64_t>(), (int)total, (int)nseg,
+                                                            seg.as<int64_t>(), seg.as<int64_t>() + 1, 0, end_bit, st));
+        int64_t vb = ceil_div(total, 256); if (vb > 16384) vb = 16384;
+        hipLaunchKernelGGL(long_values_kernel, dim3((unsigned)vb), dim3(256), 0, st, total, pos2.as<int64_t>(),
+                           reinterpret_cast<const uint8_t *>(C->x), esize, vals.as<uint8_t>());
+        hipLaunchKernelGGL(long_scatter_kernel, dim3((unsigned)nseg), dim3(256), 0, st, q0, list, C->p, cbeg.as<int64_t>(),
+                           keys2.as<int64_t>(), vals.as<uint8_t>(), esize, C->i, reinterpret_cast<uint8_t *>(C->x));
+        GBA_HIP(hipGetLastError());
+        GBA_HIP(hipStreamSynchronize(st));              // the batch's buffers go back to the pool
+        q0 = q1;
+    }
+    return GBA_SUCCESS;
+}
+
 gba_info matrix_wait(gba_matrix *C) {
     GBA_OK(require_init());
     if (!is_sparse(C)) { C->jumbled = false; return GBA_SUCCESS; }      // bitmap/full: nothing pending
@@ -188,31 +278,7 @@ gba_info matrix_wait(gba_matrix *C) {
                                lds_list.as<int64_t>(), C->p, C->i, reinterpret_cast<uint8_t *>(C->x), esize);
             GBA_HIP(hipGetLastError());
         }
-        if (h[1] > 0) {
-            // Vectors longer than the LDS sort: sorted on the host, one at a time.  The device kernels
-            // of this library never produce them (long vectors leave saxpy3 already ordered).
-            std::vector<int64_t> big(h[1]);
-            GBA_HIP(hipMemcpyAsync(big.data(), big_list.p, (size_t)h[1] * 8, hipMemcpyDeviceToHost, st));
-            GBA_HIP(hipStreamSynchronize(st));
-            for (int64_t j : big) {
-                int64_t pp[2];
-                GBA_HIP(hipMemcpy(pp, C->p + j, 16, hipMemcpyDeviceToHost));
-                const int64_t n = pp[1] - pp[0];
-                std::vector<int64_t> idx((size_t)n), ord((size_t)n);
-                std::vector<uint8_t> vals((size_t)n * esize), nv((size_t)n * esize);
-                GBA_HIP(hipMemcpy(idx.data(), C->i + pp[0], (size_t)n * 8, hipMemcpyDeviceToHost));
-                GBA_HIP(hipMemcpy(vals.data(), reinterpret_cast<uint8_t *>(C->x) + pp[0] * esize, (size_t)n * esize, hipMemcpyDeviceToHost));
-                for (int64_t t = 0; t < n; t++) ord[(size_t)t] = t;
-                std::sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) { return idx[(size_t)a] < idx[(size_t)b]; });
-                std::vector<int64_t> ni((size_t)n);
-                for (int64_t t = 0; t < n; t++) {
-                    ni[(size_t)t] = idx[(size_t)ord[(size_t)t]];
-                    for (int b = 0; b < esize; b++) nv[(size_t)t * esize + b] = vals[(size_t)ord[(size_t)t] * esize + b];
-                }
-                GBA_HIP(hipMemcpy(C->i + pp[0], ni.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-                GBA_HIP(hipMemcpy(reinterpret_cast<uint8_t *>(C->x) + pp[0] * esize, nv.data(), (size_t)n * esize, hipMemcpyHostToDevice));
-            }
-        }
+        if (h[1] > 0) GBA_OK(sort_long_vectors(C, big_list.as<int64_t>(), (int64_t)h[1], esize));
         GBA_HIP(hipStreamSynchronize(st));
     }
     C->jumbled = false;

@@ -147,6 +147,21 @@ def test_masked_heavy_vectors(gba, mkind, comp):
     assert_same(got, want, exact=True)
 
 
+def test_heavy_vectors_sorted_on_request(gba):
+    """do_sort (GrB_wait on the jumbled result): vectors longer than the LDS sort take the device
+    radix sort; the result must be the oracle's sorted C entry for entry, in order."""
+    As, Bs = _heavy_pair(60000, 4, 5000, 12, 20000, 3, seed=12)
+    A, B = _mat(As), _mat(Bs)
+    dA, dB = A.to_device(), B.to_device()
+    out, rep, _ = gba.AxB_saxpy3(None, False, True, dA, dB, "PLUS_TIMES_FP64", do_sort=1)
+    got = out.to_host()
+    for d in (dA, dB, out):
+        d.free()
+    want = oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64", wait=True)
+    assert not got.jumbled and np.diff(want.p).min() > 4096
+    assert np.array_equal(got.p, want.p) and np.array_equal(got.i, want.i) and np.array_equal(got.x, want.x)
+
+
 def test_jumbled_A_takes_the_dense_accumulator_path(gba):
     """The panel sweep needs sorted A(:,k); a jumbled A must still give the same C."""
     As, Bs = _heavy_pair(30000, 2, 2500, 8, 9000, 3, seed=7)
