@@ -4,6 +4,7 @@
   spmv      RMAT-s, A CSR fp32, x full fp32:  y = A*x (dot2, y bitmap), y += A*x (dot4, in place),
             y' += x'*A (saxpy4, scatter) -- PLUS_TIMES_FP32 through gba_mxv / gba_vxm
   tricount  L = tril(A|A', -1), C<L,struct> = L*L' PLUS_PAIR_INT64 through gba_mxm (dot3), sum(C)
+  bfs       level-synchronous BFS from the highest-degree vertex, one masked gba_vxm per level
 
 Prints one JSON line per measurement: device time per call (HIP events on the library stream, from
 the call's report), algorithmic bytes per call and the HBM rate they give.
@@ -106,12 +107,57 @@ def tricount(args):
          frac=round(gbs / HBM_PEAK_GBS, 4), workload=f"RMAT-{args.scale} ef=16 seed=42 triangle count")
 
 
+def bfs(args):
+    """Level-synchronous BFS, the LAGraph push step: q<!pi,struct,replace> = q'*A with ANY_SECONDI_INT64,
+    pi held bitmap, q sparse or bitmap (bitmap once it holds more than n/8 entries)."""
+    import graphblas_amd as g
+    from graphblas_amd import gen, Matrix, Type
+    A = gen.rmat(args.scale, 16, seed=42, type=Type.INT64, values="ones", symmetric=True, drop_diagonal=True)
+    n, nnz = A.nrows, A.nvals
+    dA = A.to_device()
+    src = int(np.argmax(np.diff(A.p)))
+    pi_b = np.zeros(n, np.int8); pi_x = np.zeros(n, np.int64)
+    pi_b[src] = 1; pi_x[src] = src
+    q = Matrix.sparse_vector(n, [src], np.array([src], np.int64))
+    levels, total_ms, visited = [], 0.0, 1
+    for level in range(64):
+        dq = q.to_device()
+        dpi = Matrix.bitmap_vector(pi_x, pi_b).to_device()
+        dw = Matrix.sparse_vector(n, [], np.zeros(0, np.int64)).to_device()
+        g.sync()
+        t0 = time.perf_counter()
+        rep = g.vxm(dw, dpi, None, "ANY_SECONDI_INT64", dq, dA, "RSC")
+        g.sync()
+        ms = (time.perf_counter() - t0) * 1e3
+        w = dw.to_host()
+        r, _, parents = w.coo()
+        for d in (dq, dpi, dw):
+            d.free()
+        levels.append(dict(level=level, frontier=int(q.nvals), found=int(len(r)), method=g.Method.NAMES[rep.method],
+                           ms=round(ms, 3), device_ms=round(rep.kernel_ms, 3), flops=int(rep.flops),
+                           phases=[round(x, 2) for x in rep.phase_ms[:7]]))
+        total_ms += ms
+        if len(r) == 0:
+            break
+        visited += len(r)
+        pi_b[r] = 1; pi_x[r] = parents
+        if len(r) > n // 8:
+            b = np.zeros(n, np.int8); x = np.zeros(n, np.int64); b[r] = 1; x[r] = parents
+            q = Matrix.bitmap_vector(x, b)
+        else:
+            q = Matrix.sparse_vector(n, r, parents)
+    dA.free()
+    emit(case="BFS push steps, ANY_SECONDI_INT64, masked by !pi", workload=f"RMAT-{args.scale} ef=16 seed=42 symmetrised",
+         n=n, nnz=nnz, source=src, visited=visited, total_ms=round(total_ms, 2),
+         GTEPS=round(nnz / total_ms / 1e6, 3), levels=levels)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["spmv", "tricount"])
+    ap.add_argument("what", choices=["spmv", "tricount", "bfs"])
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     import graphblas_amd as g
     g.init(0)
-    {"spmv": spmv, "tricount": tricount}[a.what](a)
+    {"spmv": spmv, "tricount": tricount, "bfs": bfs}[a.what](a)

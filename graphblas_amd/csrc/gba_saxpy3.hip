@@ -186,9 +186,17 @@ __device__ inline int bin_of(int64_t w, const BinLimits &L) {
     return BIN_GLOBAL;
 }
 
+// bin by work; a second measure (the flop count, when binning by exact entry count) can only move a
+// vector to a bin with more threads: a masked vector may have few entries and still many products
+__device__ inline int bin_of2(int64_t w, const BinLimits &L, const int64_t *__restrict__ work2, int64_t idx, const BinLimits &L2) {
+    int b = bin_of(w, L);
+    if (b != BIN_EMPTY && work2) { const int b2 = bin_of(work2[idx], L2); if (b2 > b) b = b2; }
+    return b;
+}
+
 __global__ void __launch_bounds__(256)
 bin_count_kernel(int64_t nvec, const int64_t *__restrict__ work, bool work_is_pointer_diff, BinLimits L,
-                 unsigned long long *__restrict__ counts) {
+                 const int64_t *__restrict__ work2, BinLimits L2, unsigned long long *__restrict__ counts) {
     __shared__ unsigned int lc[NBINS];
     if (threadIdx.x < NBINS) lc[threadIdx.x] = 0;
     __syncthreads();
@@ -196,7 +204,7 @@ bin_count_kernel(int64_t nvec, const int64_t *__restrict__ work, bool work_is_po
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; idx < nvec; idx += stride) {
         const int64_t w = work_is_pointer_diff ? (work[idx + 1] - work[idx]) : work[idx];
-        atomicAdd(&lc[bin_of(w, L)], 1u);
+        atomicAdd(&lc[bin_of2(w, L, work2, idx, L2)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < NBINS && lc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)lc[threadIdx.x]);
@@ -204,12 +212,13 @@ bin_count_kernel(int64_t nvec, const int64_t *__restrict__ work, bool work_is_po
 
 __global__ void __launch_bounds__(256)
 bin_fill_kernel(int64_t nvec, const int64_t *__restrict__ work, bool work_is_pointer_diff, BinLimits L,
+                const int64_t *__restrict__ work2, BinLimits L2,
                 unsigned long long *__restrict__ cursors, int64_t *__restrict__ lists) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; idx < nvec; idx += stride) {
         const int64_t w = work_is_pointer_diff ? (work[idx + 1] - work[idx]) : work[idx];
-        const int b = bin_of(w, L);
+        const int b = bin_of2(w, L, work2, idx, L2);
         if (b != BIN_EMPTY) {
             unsigned long long pos = atomicAdd(&cursors[b], 1ull);
             lists[pos] = idx;
@@ -224,14 +233,15 @@ struct Bins {
     const int64_t *list(int b) const { return lists.as<int64_t>() + start[b]; }
 };
 
-static gba_info build_bins(int64_t nvec, const int64_t *work, bool ptr_diff, BinLimits L, Bins *bins) {
+static gba_info build_bins(int64_t nvec, const int64_t *work, bool ptr_diff, BinLimits L, Bins *bins,
+                           const int64_t *work2 = nullptr, BinLimits L2 = BinLimits{0, 0, 0}) {
     hipStream_t st = ctx().stream;
     DevBuf cnt; GBA_OK(cnt.alloc(NBINS * 8));
     GBA_HIP(hipMemsetAsync(cnt.p, 0, NBINS * 8, st));
     GBA_OK(bins->lists.alloc((size_t)(nvec > 0 ? nvec : 1) * 8));
     if (nvec == 0) return GBA_SUCCESS;
     int64_t blocks = ceil_div(nvec, 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, work, ptr_diff, L,
+    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, work, ptr_diff, L, work2, L2,
                        cnt.as<unsigned long long>());
     unsigned long long h[NBINS];
     GBA_HIP(hipMemcpyAsync(h, cnt.p, NBINS * 8, hipMemcpyDeviceToHost, st));
@@ -245,7 +255,7 @@ static gba_info build_bins(int64_t nvec, const int64_t *work, bool ptr_diff, Bin
         if (b != BIN_EMPTY) off += (int64_t)h[b];
     }
     GBA_HIP(hipMemcpyAsync(cnt.p, cur, NBINS * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, work, ptr_diff, L,
+    hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, work, ptr_diff, L, work2, L2,
                        cnt.as<unsigned long long>(), bins->lists.as<int64_t>());
     GBA_HIP(hipGetLastError());
     GBA_HIP(hipStreamSynchronize(st));
@@ -693,6 +703,127 @@ __global__ void fill_acc_kernel(ACC *p, int64_t n, ACC v) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; idx < n; idx += stride) p[idx] = v;
+}
+
+// ------------------------------------------------------------- team kernels --
+// A handful of very heavy vectors -- a frontier step w = A*q has ONE -- would each occupy a single
+// workgroup while the rest of the chip idles.  The CPU forms a team of fine tasks per such vector that
+// share one Hf/Hx workspace through atomics (Source/GB_AxB_saxpy3_slice_balanced.c:560-771,
+// Source/Template/GB_AxB_saxpy3_fineGus_phase2.c).  Here the whole grid is the team: every wavefront takes
+// neighbours k of B(:,j) and scatters A(:,k) into a dense accumulator Hx[cvlen] with the monoid's atomic,
+// marking touched indices in the bitmap Hf; columns longer than TEAM_LONG are shared by the whole grid.
+// The products are formed once, during the symbolic phase (the count is the number of marks); the
+// numeric phase only gathers.  Entries come out in no particular order (C is returned jumbled).
+static constexpr int TEAM_MAX_VECTORS = 32;
+static constexpr int64_t TEAM_MIN_FLOPS = 200000;
+static constexpr int TEAM_THREADS = 256;
+static constexpr int64_t TEAM_LONG = 8192;
+
+__global__ void __launch_bounds__(256)
+team_select_kernel(int64_t nvec, const int64_t *__restrict__ vflops, int64_t min_flops,
+                   unsigned long long *__restrict__ count, int64_t *__restrict__ list, int cap) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx < nvec; idx += stride) {
+        if (vflops[idx] > min_flops) {
+            const unsigned long long q = atomicAdd(count, 1ull);
+            if (q < (unsigned long long)cap) list[q] = idx;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+zero_listed_kernel(int n, const int64_t *__restrict__ list, int64_t *__restrict__ work) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) work[list[q]] = 0;
+}
+
+template <class S>
+__device__ inline void team_update(const S &sr, const SpView &A, const SpView &B, const MaskView &M, bool apat, bool bpat,
+                                   int64_t j, int64_t k, int64_t pA, int64_t pB,
+                                   typename S::acc_t *__restrict__ Hx, uint64_t *__restrict__ Hf) {
+    const int64_t i = A.i[pA];
+    if (!mask_allows(M, i, j)) return;
+    sr.atomic(&Hx[i], product(sr, A, B, apat, bpat, i, k, j, pA, pB));
+    const uint64_t bit = 1ull << (i & 63);
+    if (!(ld_agent(&Hf[i >> 6]) & bit)) atomicOr(reinterpret_cast<unsigned long long *>(&Hf[i >> 6]), (unsigned long long)bit);
+}
+
+template <class S>
+__global__ void __launch_bounds__(TEAM_THREADS)
+team_product_kernel(S sr, int64_t j, SpView A, SpView B, MaskView M, typename S::acc_t *__restrict__ Hx,
+                    uint64_t *__restrict__ Hf, unsigned long long *__restrict__ nlong, int64_t *__restrict__ longq) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t pB0 = B.p[j], deg = B.p[j + 1] - pB0;
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    for (int64_t t = gw; t < deg; t += nw) {
+        const int64_t k = B.i[pB0 + t];
+        const int64_t pA0 = A.p[k], pA1 = A.p[k + 1];
+        if (pA1 - pA0 > TEAM_LONG) {
+            if (lane == 0) longq[atomicAdd(nlong, 1ull)] = t;
+            continue;
+        }
+        for (int64_t pA = pA0 + lane; pA < pA1; pA += 64) team_update(sr, A, B, M, apat, bpat, j, k, pA, pB0 + t, Hx, Hf);
+    }
+}
+
+template <class S>
+__global__ void __launch_bounds__(TEAM_THREADS)
+team_long_kernel(S sr, int64_t j, SpView A, SpView B, MaskView M, typename S::acc_t *__restrict__ Hx,
+                 uint64_t *__restrict__ Hf, const unsigned long long *__restrict__ nlong, const int64_t *__restrict__ longq) {
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    const int64_t pB0 = B.p[j];
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    const unsigned long long n = *nlong;
+    for (unsigned long long q = 0; q < n; q++) {
+        const int64_t t = longq[q], k = B.i[pB0 + t];
+        const int64_t pA1 = A.p[k + 1];
+        for (int64_t pA = A.p[k] + gt; pA < pA1; pA += nt) team_update(sr, A, B, M, apat, bpat, j, k, pA, pB0 + t, Hx, Hf);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+team_count_kernel(int64_t nf, const uint64_t *__restrict__ Hf, unsigned long long *__restrict__ out) {
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (; w < nf; w += stride) c += (unsigned long long)__builtin_popcountll(Hf[w]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+template <class S>
+__global__ void __launch_bounds__(256)
+team_gather_kernel(int64_t nf, const uint64_t *__restrict__ Hf, const typename S::acc_t *__restrict__ Hx,
+                   unsigned long long *__restrict__ cursor, int64_t pC0, int64_t *__restrict__ Ci,
+                   typename S::z_t *__restrict__ Cx) {
+    using Z = typename S::z_t;
+    const int lane = threadIdx.x & 63;
+    int64_t w0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; w0 < nf; w0 += stride) {
+        const int64_t w = w0 + lane;
+        uint64_t fw = (w < nf) ? Hf[w] : 0ull;
+        const int c = __builtin_popcountll(fw);
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
+        const int total = __shfl(incl, 63, 64);
+        if (total == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)total);
+        base = __shfl(base, 0, 64);
+        int64_t pC = pC0 + (int64_t)base + incl - c;
+        while (fw) {
+            const int64_t i = (w << 6) + __builtin_ctzll(fw);
+            fw &= fw - 1;
+            Ci[pC] = i;
+            Cx[pC] = (Z)Hx[i];
+            pC++;
+        }
+    }
 }
 
 // ------------------------------------------------------------ panel kernels --
@@ -1365,10 +1496,69 @@ struct Saxpy3Plan {
     bool A_sorted = false;                  // vectors of A in index order: panel kernels usable
     int64_t maxdeg = 0;                     // longest vector of B
     const int64_t *vflops = nullptr;        // per-vector flop count (device)
+    // team vectors: ids (host), their workspaces one after the other (device)
+    std::vector<int64_t> team;
+    void *team_Hx = nullptr; uint64_t *team_Hf = nullptr;
     const int64_t *bstart = nullptr;        // panel boundaries of vector j: bounds[bstart[j] .. bstart[j+1])
     int64_t *bounds = nullptr;
     unsigned long long panel_stats[3] = {0, 0, 0};   // rows pulled, panels swept, panels redone
 };
+
+template <class S>
+static gba_info run_team_products(const S &sr, Saxpy3Plan &P, int64_t *cnt) {
+    using ACC = typename S::acc_t;
+    hipStream_t st = ctx().stream;
+    const int64_t nf = (P.cvlen + 63) >> 6;
+    const int64_t nteam = (int64_t)P.team.size();
+    ACC *Hx = reinterpret_cast<ACC *>(P.team_Hx);
+    const int64_t nacc = nteam * P.cvlen;
+    int64_t fb = ceil_div(nacc, 256); if (fb > 8192) fb = 8192;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(fill_acc_kernel<ACC>), dim3((unsigned)fb), dim3(256), 0, st, Hx, nacc, (ACC)sr.identity());
+    GBA_HIP(hipMemsetAsync(P.team_Hf, 0, (size_t)nteam * nf * 8, st));
+    DevBuf nlong, longq;
+    GBA_OK(nlong.alloc((size_t)nteam * 8));
+    GBA_OK(longq.alloc((size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
+    GBA_HIP(hipMemsetAsync(nlong.p, 0, (size_t)nteam * 8, st));
+    const unsigned grid = (unsigned)(ctx().num_cu * 8);
+    int64_t cb = ceil_div(nf, 256); if (cb > 4096) cb = 4096;
+    for (int64_t q = 0; q < nteam; q++) {
+        const int64_t j = P.team[(size_t)q];
+        ACC *hx = Hx + q * P.cvlen; uint64_t *hf = P.team_Hf + q * nf;
+        unsigned long long *nl = nlong.as<unsigned long long>() + q;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(team_product_kernel<S>), dim3(grid), dim3(TEAM_THREADS), 0, st, sr, j, P.A, P.B, P.M,
+                           hx, hf, nl, longq.as<int64_t>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(team_long_kernel<S>), dim3(grid), dim3(TEAM_THREADS), 0, st, sr, j, P.A, P.B, P.M,
+                           hx, hf, nl, longq.as<int64_t>());
+        hipLaunchKernelGGL(team_count_kernel, dim3((unsigned)cb), dim3(256), 0, st, nf, hf,
+                           reinterpret_cast<unsigned long long *>(cnt + j));
+    }
+    GBA_HIP(hipGetLastError());
+    GBA_HIP(hipStreamSynchronize(st));          // longq is released on return
+    return GBA_SUCCESS;
+}
+
+template <class S>
+static gba_info run_team_gather(const S &sr, Saxpy3Plan &P) {
+    using Z = typename S::z_t; using ACC = typename S::acc_t;
+    hipStream_t st = ctx().stream;
+    const int64_t nf = (P.cvlen + 63) >> 6;
+    const int64_t nteam = (int64_t)P.team.size();
+    DevBuf cursor, cp;
+    GBA_OK(cursor.alloc((size_t)nteam * 8));
+    GBA_HIP(hipMemsetAsync(cursor.p, 0, (size_t)nteam * 8, st));
+    int64_t gb = ceil_div(nf, 256); if (gb > 4096) gb = 4096;
+    for (int64_t q = 0; q < nteam; q++) {
+        const int64_t j = P.team[(size_t)q];
+        int64_t pC0 = 0;
+        GBA_OK(dev_read_i64(P.Cp + j, &pC0));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(team_gather_kernel<S>), dim3((unsigned)gb), dim3(256), 0, st, nf,
+                           P.team_Hf + q * nf, reinterpret_cast<const ACC *>(P.team_Hx) + q * P.cvlen,
+                           cursor.as<unsigned long long>() + q, pC0, P.Ci, reinterpret_cast<Z *>(P.Cx));
+    }
+    GBA_HIP(hipGetLastError());
+    GBA_HIP(hipStreamSynchronize(st));
+    return GBA_SUCCESS;
+}
 
 template <class S>
 static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
@@ -1558,13 +1748,50 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     // bound on nnz C(:,j) whatever the mask does, which is what sizes the hash tables.
     DevBuf vflops; GBA_OK(vflops.alloc((size_t)(nvec + 1) * 8));
     GBA_OK(saxpy3_flopcount(nullptr, vflops.as<int64_t>(), nullptr, false, A, B));
+    // a few very heavy vectors: the whole grid works on each of them (team kernels)
+    DevBuf team_list, team_Hx, team_Hf, symwork;
+    const int64_t *symflops = vflops.as<int64_t>();
+    {
+        DevBuf tc; GBA_OK(tc.alloc(8));
+        GBA_HIP(hipMemsetAsync(tc.p, 0, 8, st));
+        GBA_OK(team_list.alloc(TEAM_MAX_VECTORS * 8));
+        if (nvec > 0) {
+            int64_t blocks = ceil_div(nvec, 256); if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(team_select_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, vflops.as<int64_t>(),
+                               TEAM_MIN_FLOPS, tc.as<unsigned long long>(), team_list.as<int64_t>(), TEAM_MAX_VECTORS);
+        }
+        int64_t nteam = 0;
+        GBA_OK(dev_read_i64(tc.as<int64_t>(), &nteam));
+        const size_t acc_size = type_size(c.ztype) < 4 ? 4 : type_size(c.ztype);
+        const int64_t nf = (P.cvlen + 63) >> 6;
+        size_t free_b = 0, total_b = 0, idle_b = 0;
+        GBA_HIP(hipMemGetInfo(&free_b, &total_b));
+        gba_pool_stats(&idle_b, nullptr);
+        const size_t need = (size_t)nteam * ((size_t)P.cvlen * acc_size + (size_t)nf * 8);
+        int64_t team_max = TEAM_MAX_VECTORS;                 // GBA_TEAM_MAX_VECTORS=0 turns the team path off (tests)
+        if (const char *e = getenv("GBA_TEAM_MAX_VECTORS")) { team_max = atoll(e); if (team_max > TEAM_MAX_VECTORS) team_max = TEAM_MAX_VECTORS; }
+        if (nteam > 0 && nteam <= team_max && need < (free_b + idle_b) / 4) {
+            P.team.resize((size_t)nteam);
+            GBA_HIP(hipMemcpyAsync(P.team.data(), team_list.p, (size_t)nteam * 8, hipMemcpyDeviceToHost, st));
+            GBA_HIP(hipStreamSynchronize(st));
+            GBA_OK(team_Hx.alloc((size_t)nteam * (size_t)P.cvlen * acc_size));
+            GBA_OK(team_Hf.alloc((size_t)nteam * (size_t)nf * 8));
+            P.team_Hx = team_Hx.p; P.team_Hf = team_Hf.as<uint64_t>();
+            // the bins must not see them
+            GBA_OK(symwork.alloc((size_t)(nvec + 1) * 8));
+            GBA_HIP(hipMemcpyAsync(symwork.p, vflops.p, (size_t)(nvec + 1) * 8, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(zero_listed_kernel, dim3(1), dim3(256), 0, st, (int)nteam, team_list.as<int64_t>(), symwork.as<int64_t>());
+            GBA_HIP(hipGetLastError());
+            symflops = symwork.as<int64_t>();
+        }
+    }
     // With sorted A the bitmap panel kernel also takes the vectors of the second block bin: it has no table to
     // clear per vector and records the numeric panel boundaries.
     const int64_t sym_blk2_max = A->jumbled ? SYM_BLK2_MAX : SYM_BLK1_MAX;
-    GBA_OK(build_bins(nvec, vflops.as<int64_t>(), false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, sym_blk2_max}, &P.sym));
+    GBA_OK(build_bins(nvec, symflops, false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, sym_blk2_max}, &P.sym));
     P.A_sorted = !A->jumbled;
     P.vflops = vflops.as<int64_t>();
-    if (P.sym.count[BIN_GLOBAL] > 0) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
+    if (P.sym.count[BIN_GLOBAL] > 0 || !P.team.empty()) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
     // the panel kernels read the indices of A from a 32-bit copy (vlen < 2^31 was checked above)
     DevBuf ai32;
     auto narrow_A = [&]() -> gba_info {
@@ -1586,7 +1813,7 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         GBA_OK(bstart.alloc((size_t)(nvec + 1) * 8));
         int64_t blocks = ceil_div(nvec + 1, 256); if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(bounds_room_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, vflops.as<int64_t>(),
-                           P.cvlen, sym_blk2_max, bstart.as<int64_t>());
+                           P.cvlen, sym_blk2_max, bstart.as<int64_t>());     // team vectors get room too; unused
         GBA_HIP(hipGetLastError());
         GBA_OK(dev_cumsum_i64(bstart.as<int64_t>(), nvec, st));
         int64_t room = 0;
@@ -1601,10 +1828,24 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     DevBuf Cp; GBA_OK(Cp.alloc((size_t)(nvec + 1) * 8));
     GBA_HIP(hipMemsetAsync(Cp.p, 0, (size_t)(nvec + 1) * 8, st));
     GBA_OK(run_symbolic(P, Cp.as<int64_t>()));
+    if (!P.team.empty()) GBA_OK(with_semiring(c, [&](auto sr) -> gba_info { return run_team_products(sr, P, Cp.as<int64_t>()); }));
     const int e2 = clock.mark();
 
     // numeric bins use the exact counts, taken before the prefix sum
-    GBA_OK(build_bins(nvec, Cp.as<int64_t>(), false, BinLimits{NUM_WAVE_MAX, NUM_BLK1_MAX, NUM_BLK2_MAX}, &P.num));
+    {
+        const int64_t *numwork = Cp.as<int64_t>();
+        DevBuf nw;
+        if (!P.team.empty()) {
+            GBA_OK(nw.alloc((size_t)(nvec + 1) * 8));
+            GBA_HIP(hipMemcpyAsync(nw.p, Cp.p, (size_t)(nvec + 1) * 8, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(zero_listed_kernel, dim3(1), dim3(256), 0, st, (int)P.team.size(), team_list.as<int64_t>(), nw.as<int64_t>());
+            GBA_HIP(hipGetLastError());
+            numwork = nw.as<int64_t>();
+        }
+        // products per thread stay bounded: by flops a vector may need a larger bin than its entry count asks for
+        GBA_OK(build_bins(nvec, numwork, false, BinLimits{NUM_WAVE_MAX, NUM_BLK1_MAX, NUM_BLK2_MAX}, &P.num,
+                          vflops.as<int64_t>(), BinLimits{2048, 16384, 65536}));
+    }
     if (P.num.count[BIN_GLOBAL] > 0 && P.maxdeg == 0) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
     if (P.num.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) GBA_OK(narrow_A());
 
@@ -1622,6 +1863,7 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     // phase 5: numeric
     if (cnz > 0) {
         GBA_OK(with_semiring(c, [&](auto sr) -> gba_info { return run_numeric(sr, P); }));
+        if (!P.team.empty()) GBA_OK(with_semiring(c, [&](auto sr) -> gba_info { return run_team_gather(sr, P); }));
     }
     GBA_HIP(hipStreamSynchronize(st));
     if (rep) {

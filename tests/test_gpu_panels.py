@@ -13,6 +13,14 @@ from util import assert_same
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _panel_path_only(monkeypatch, request):
+    """A handful of very heavy vectors would take the team kernels (whole grid per vector); the cases
+    here are about the panel kernels, so that path is switched off unless a test asks for it."""
+    if "team" not in request.node.name:
+        monkeypatch.setenv("GBA_TEAM_MAX_VECTORS", "0")
+
+
 def _heavy_pair(n, ncols, deg, nhubs, hub_len, light_len, seed, dense_cols=0):
     """A (n x n) with `nhubs` long columns and short ones elsewhere; B (n x ncols) whose columns
     each name `deg` columns of A, hubs included: every C(:,j) is a heavy vector."""
@@ -144,6 +152,38 @@ def test_masked_heavy_vectors(gba, mkind, comp):
     got, rep = _run(gba, A, B, "PLUS_TIMES_FP64", M=M, comp=comp, struct=False)
     want = oracle.saxpy3(M, comp, False, A, B, "PLUS_TIMES_FP64")
     assert np.diff(want.p).max() > 4096
+    assert_same(got, want, exact=True)
+
+
+@pytest.mark.parametrize("sr,t", [
+    ("PLUS_TIMES_FP64", Type.FP64), ("PLUS_TIMES_INT8", Type.INT8), ("MIN_PLUS_FP64", Type.FP64),
+    ("ANY_PAIR_BOOL", Type.BOOL), ("MAX_SECONDI_INT64", Type.INT64), ("LOR_LAND_BOOL", Type.BOOL),
+])
+def test_team_kernels_for_a_few_hub_vectors(gba, sr, t):
+    """Up to 32 vectors of > 2e5 multiply-adds each are computed by the whole grid (dense accumulator
+    + bitmap, monoid atomics); lighter vectors of the same product keep their own paths."""
+    As, Bs = _heavy_pair(60000, 5, 5000, 12, 30000, 3, seed=13)
+    light = sp.random(60000, 40, density=2e-4, random_state=np.random.default_rng(3), format="csc")
+    light.data[:] = 2
+    Bs = sp.hstack([Bs, light]).tocsc()
+    A, B = _mat(As, t), _mat(Bs, t)
+    got, rep = _run(gba, A, B, sr)
+    want = oracle.saxpy3(None, False, False, A, B, sr)
+    assert rep.bin_vectors[3] == 0 and np.diff(want.p)[:5].min() > 8192      # hub vectors were not binned
+    assert_same(got, want, exact=(not sr.startswith("ANY")), check_values=(not sr.startswith("ANY")), what=sr)
+
+
+@pytest.mark.parametrize("comp", [False, True])
+def test_team_kernels_masked_frontier_step(gba, comp):
+    """One output vector with a bitmap mask: the BFS/SSSP frontier shape."""
+    n = 50000
+    As, Bs = _heavy_pair(n, 1, 4000, 10, 30000, 3, seed=14)
+    A, B = _mat(As), _mat(Bs)
+    rng = np.random.default_rng(15)
+    M = Matrix.dense(np.ones((n, 1), np.int8), present=rng.random((n, 1)) < 0.4, by_row=False)
+    got, rep = _run(gba, A, B, "MIN_PLUS_FP64", M=M, comp=comp, struct=True)
+    want = oracle.saxpy3(M, comp, True, A, B, "MIN_PLUS_FP64")
+    assert rep.bin_vectors[3] == 0 and want.nvals > 4096
     assert_same(got, want, exact=True)
 
 
