@@ -94,6 +94,33 @@ flopcount_wave_kernel(int64_t nvec, const int64_t *__restrict__ Bp, const int64_
     if (lane == 0) vflops[kk] = base + s;
 }
 
+// few, long vectors (a frontier step has one): several workgroups share a vector; vflops must start at zero
+__global__ void __launch_bounds__(256)
+flopcount_shared_kernel(int64_t nvec, const int64_t *__restrict__ Bp, const int64_t *__restrict__ Bi,
+                        const int64_t *__restrict__ Ap, const int64_t *__restrict__ Mp,
+                        int64_t *__restrict__ vflops, unsigned long long *__restrict__ Mwork) {
+    const int64_t kk = blockIdx.y;
+    const int64_t pB0 = Bp[kk], pB1 = Bp[kk + 1];
+    const int64_t bjnz = pB1 - pB0;
+    if (bjnz == 0) return;
+    int64_t s = 0;
+    for (int64_t pB = pB0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pB < pB1; pB += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = Bi[pB];
+        s += Ap[k + 1] - Ap[k];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t base = bjnz;
+        if (Mp) {
+            const int64_t mjnz = Mp[kk + 1] - Mp[kk];
+            if (mjnz > 0) { base = mjnz; atomicAdd(Mwork, (unsigned long long)mjnz); }
+        }
+        s += base;
+    }
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(reinterpret_cast<unsigned long long *>(&vflops[kk]), (unsigned long long)s);
+}
+
 // one thread per vector; mirrors the sequential arithmetic of
 // Source/GB_AxB_saxpy3_flopcount.c:239-383 including the (int64 += double) steps
 __global__ void __launch_bounds__(256)
@@ -147,8 +174,16 @@ gba_info saxpy3_flopcount(int64_t *Mwork_out, int64_t *Bflops, const gba_matrix 
                                Bflops, mw.as<unsigned long long>());
         } else {
             const int64_t *Mp = (M && !M_is_dense) ? M->p : nullptr;
-            hipLaunchKernelGGL(flopcount_wave_kernel, dim3((unsigned)ceil_div(nvec * 64, 256)), dim3(256), 0, st,
-                               nvec, B->p, B->i, A->p, Mp, Bflops, mw.as<unsigned long long>());
+            const int64_t avg = B->nvals / nvec;
+            if (nvec <= 1024 && avg > 4096) {
+                int64_t per = ceil_div(avg, 2048); if (per > 256) per = 256;
+                GBA_HIP(hipMemsetAsync(Bflops, 0, (size_t)nvec * 8, st));
+                hipLaunchKernelGGL(flopcount_shared_kernel, dim3((unsigned)per, (unsigned)nvec), dim3(256), 0, st,
+                                   nvec, B->p, B->i, A->p, Mp, Bflops, mw.as<unsigned long long>());
+            } else {
+                hipLaunchKernelGGL(flopcount_wave_kernel, dim3((unsigned)ceil_div(nvec * 64, 256)), dim3(256), 0, st,
+                                   nvec, B->p, B->i, A->p, Mp, Bflops, mw.as<unsigned long long>());
+            }
         }
         GBA_HIP(hipGetLastError());
     }
