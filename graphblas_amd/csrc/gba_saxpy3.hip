@@ -901,6 +901,17 @@ static_assert(SYM_PANEL_WIDTH <= PANEL_MAX_WIDTH, "symbolic panel too wide for 3
 static_assert(SYM_WORDS_PER_THREAD * PANEL_THREADS == SYM_PANEL_WORDS && SYM_WORDS_PER_THREAD * 32 < NUM_PANEL_FIT,
               "each thread owns a bitmap slice that can hold at most one boundary");
 
+// Optional in-kernel stopwatch (thread 0, 100 MHz ticks) for tuning: build with -DGBA_PANEL_TICKS and run with
+// GBA_PANEL_PROF=1; slots: 0 search, 1 wait for the other waves' search, 2 prefix sum, 3 products,
+// 4 wait for the other waves' products, 5 emit, 6 whole panels.
+#ifdef GBA_PANEL_TICKS
+#define GBA_TICK(var) const unsigned long long var = wall_clock64()
+#define GBA_TOCK(S, slot, a, b) do { if (threadIdx.x == 0) (S)->tk[slot] += (b) - (a); } while (0)
+#else
+#define GBA_TICK(var) do {} while (0)
+#define GBA_TOCK(S, slot, a, b) do {} while (0)
+#endif
+
 // runs of the current panel waiting to be expanded (LDS)
 struct PanelSegs {
     unsigned long long where[PANEL_SEGCAP];   // position of the run in A (high 40 bits) | neighbour ordinal (low 24)
@@ -908,8 +919,12 @@ struct PanelSegs {
     uint32_t wsum[PANEL_THREADS / 64];
     unsigned long long wmask[PANEL_THREADS / 64][PANEL_UNROLL_MAX];   // per wave: products of the window at which a run starts
     int nseg;
+    uint32_t wnext;                           // next window of products to hand to a wave
     int more;                                 // some neighbour still has entries below the end of the sweep
     int overflow;                             // the numeric table ran out of room
+#ifdef GBA_PANEL_TICKS
+    unsigned long long tk[8];
+#endif
 };
 
 struct PanelCursors {
@@ -942,6 +957,7 @@ template <int PANEL_UNROLL, class Load, class Apply>
 __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSegs *S, Load load, Apply apply) {
     static_assert(PANEL_SEGCAP == 4 * PANEL_THREADS, "four queue entries per thread in the scan");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    GBA_TICK(tke0);
     const int b4 = tid * 4;
     uint32_t v[4], s = 0;
 #pragma unroll
@@ -957,30 +973,48 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
     uint32_t run = woff + incl - s;
 #pragma unroll
     for (int q = 0; q < 4; q++) if (b4 + q < n) { S->off[b4 + q] = run; run += v[q]; }
-    if (tid == 0) S->nseg = 0;
+    if (tid == 0) { S->nseg = 0; S->wnext = 0; }
     __syncthreads();
+    GBA_TICK(tke1);
+    GBA_TOCK(S, 2, tke0, tke1);
     const int32_t *__restrict__ Ai = A.i32;
-    // Each wave owns a contiguous slab of windows of WIN consecutive products.  It bisects the
-    // prefix sums once, for the run holding its first product; after that the runs that START
-    // inside a window are read 64 at a time (one conflict-free LDS read), marked in WIN bits, and
-    // a product's run is the window's first run plus the number of marks at or before it.
+    // The products are cut into windows of WIN consecutive ones.  With few windows (a numeric panel has
+    // a few dozen) the waves take them from an LDS counter as they get free -- the time per window
+    // varies with the hash probes and the cache misses it meets; with many (symbolic panels) every
+    // wave owns a contiguous slab.  A wave bisects the prefix sums for the run holding the first product
+    // of a window (uniform address: broadcast reads; inside a slab the next window's run follows from
+    // the marks).  The runs that START inside the window are read 64 at a time (one conflict-free LDS
+    // read), marked in WIN bits, and a product's run is the window's first run plus the number of
+    // marks at or before it.
     constexpr uint32_t WIN = 64 * PANEL_UNROLL;
     constexpr int NWAVES = PANEL_THREADS / 64;
     const uint32_t nwin = (uint32_t)(((uint64_t)T + WIN - 1) / WIN);
-    const uint32_t per = (nwin + NWAVES - 1) / NWAVES;
-    uint32_t win = (uint32_t)wv * per;
-    const uint32_t win_end = (win + per < nwin) ? win + per : nwin;
-    if (win < win_end) {
-        uint64_t w0 = (uint64_t)win * WIN;
+    {
+        const bool dynamic = nwin < (uint32_t)(NWAVES * 16);
+        const uint32_t per = (nwin + NWAVES - 1) / NWAVES;
+        uint32_t win = (uint32_t)wv * per;
+        const uint32_t win_end = (win + per < nwin) ? win + per : nwin;
         int top = 1;                                    // largest power of two below n (bisection stride)
         while (top * 2 < n) top <<= 1;
-        int sb = 0;                                     // run holding product w0: largest s with off[s] <= w0
-        for (int step = top; step > 0; step >>= 1) {
-            const int idx = sb + step;
-            if (idx < n && (uint64_t)S->off[idx] <= w0) sb = idx;
-        }
+        int sb = 0;                                     // windows come in increasing order: never search below the last run
+        bool placed = false;
         unsigned long long *wm = S->wmask[wv];
-        for (; win < win_end; win++, w0 += WIN) {
+        while (true) {
+            if (dynamic) {
+                if (lane == 0) win = atomicAdd(&S->wnext, 1u);
+                win = __shfl(win, 0, 64);
+                if (win >= nwin) break;
+            } else if (win >= win_end) {
+                break;
+            }
+            const uint64_t w0 = (uint64_t)win * WIN;
+            if (dynamic || !placed) {
+                for (int step = top; step > 0; step >>= 1) {    // largest s >= sb with off[s] <= w0
+                    const int idx = sb + step;
+                    if (idx < n && (uint64_t)S->off[idx] <= w0) sb = idx;
+                }
+                placed = true;
+            }
             const uint64_t wend = w0 + WIN;
             if (lane < PANEL_UNROLL) wm[lane] = 0ull;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1028,10 +1062,13 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
 #pragma unroll
             for (int u = 0; u < PANEL_UNROLL; u++) payload[u] = load(ii[u], pA[u], pB[u]);
             apply(ii, payload, ok);
-            sb += starts + (edge ? 1 : 0);
+            if (!dynamic) { sb += starts + (edge ? 1 : 0); win++; }
         }
     }
+    GBA_TICK(tke2);
     __syncthreads();
+    GBA_TICK(tke3);
+    GBA_TOCK(S, 3, tke1, tke2); GBA_TOCK(S, 4, tke2, tke3);
 }
 
 // Visit the products A(i,k)*B(k,j) with ibeg <= i < pend that have not been
@@ -1049,6 +1086,7 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
     const int tid = threadIdx.x, lane = tid & 63;
     const int32_t *__restrict__ Ai = A.i32;
     for (int64_t t0 = 0; t0 < deg; t0 += PANEL_STEP) {
+        GBA_TICK(tk0);
         int64_t c[PANEL_NPT], e[PANEL_NPT], nv[PANEL_NPT], stop[PANEL_NPT];
         bool live[PANEL_NPT], need[PANEL_NPT];
 #pragma unroll
@@ -1154,7 +1192,10 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
                 }
             }
         }
+        GBA_TICK(tk1);
         __syncthreads();
+        GBA_TICK(tk2);
+        GBA_TOCK(S, 0, tk0, tk1); GBA_TOCK(S, 1, tk1, tk2);
         const int ns = S->nseg;
         const bool last = t0 + PANEL_STEP >= deg;
         if (ns >= PANEL_SEGCAP - PANEL_STEP || (last && ns > 0)) {
@@ -1204,6 +1245,9 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int w = tid; w < SYM_PANEL_WORDS; w += PANEL_THREADS) bm[w] = 0;
     if (tid == 0) { Q.nseg = 0; Q.overflow = 0; }
+#ifdef GBA_PANEL_TICKS
+    if (tid == 0) for (int q = 0; q < 8; q++) Q.tk[q] = 0;
+#endif
     PanelCursors pc(scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg, maxdeg);
     const int64_t npanels = (cvlen + SYM_PANEL_WIDTH - 1) / SYM_PANEL_WIDTH;
     while (true) {
@@ -1353,6 +1397,10 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
     PanelCursors pc(scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg, maxdeg);
     for (int s = threadIdx.x; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
     if (threadIdx.x == 0) Q.nseg = 0;
+#ifdef GBA_PANEL_TICKS
+    if (threadIdx.x == 0) for (int q = 0; q < 8; q++) Q.tk[q] = 0;
+    const unsigned long long tkk = wall_clock64();
+#endif
     while (true) {
         if (threadIdx.x == 0) row = (int64_t)atomicAdd(next, 1ull);
         __syncthreads();
@@ -1391,6 +1439,7 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
             if (lim > iend) lim = iend;
             const int64_t pend = (lim >= cvlen) ? PANEL_INF : lim;
             if (threadIdx.x == 0) { Q.overflow = 0; Q.more = 0; out_cursor = 0; }
+            GBA_TICK(tkp0);
             __syncthreads();
             panel_walk<NUM_PANEL_UNROLL>(A, B, pB0, deg, ibeg, pend, iend, first, pc, &Q,
                 [&](int32_t i, int64_t pA, int64_t pB) -> Z {
@@ -1436,6 +1485,7 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                 continue;
             }
             // emit the panel (wave-aggregated positions, coalesced stores) and leave the table clean
+            GBA_TICK(tkp1);
             for (int s = threadIdx.x; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) {
                 const int32_t key = keys[s];
                 const bool occ = (key != HASH_EMPTY);
@@ -1452,6 +1502,8 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                 }
             }
             __syncthreads();
+            GBA_TICK(tkp2);
+            GBA_TOCK(&Q, 5, tkp1, tkp2); GBA_TOCK(&Q, 6, tkp0, tkp2);
             const int d = out_cursor;
             const int more = Q.more;
             pC += d;
@@ -1473,6 +1525,9 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
         }
     }
     if (threadIdx.x == 0) { atomicAdd(&next[1], st_panels); atomicAdd(&next[2], st_overflows); }
+#ifdef GBA_PANEL_TICKS
+    if (threadIdx.x == 0) { Q.tk[7] = wall_clock64() - tkk; for (int q = 0; q < 8; q++) atomicAdd(&next[3 + q], Q.tk[q]); }
+#endif
 }
 
 // ------------------------------------------------------------------ driver --
@@ -1536,7 +1591,7 @@ struct Saxpy3Plan {
     void *team_Hx = nullptr; uint64_t *team_Hf = nullptr;
     const int64_t *bstart = nullptr;        // panel boundaries of vector j: bounds[bstart[j] .. bstart[j+1])
     int64_t *bounds = nullptr;
-    unsigned long long panel_stats[3] = {0, 0, 0};   // rows pulled, panels swept, panels redone
+    unsigned long long panel_stats[11] = {0};        // tasks pulled, panels swept, panels redone, stopwatch slots
 };
 
 template <class S>
@@ -1647,8 +1702,8 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         if (nblocks > ntasks) nblocks = ntasks;
         DevBuf scratch, next;
         GBA_OK(scratch.alloc((size_t)nblocks * PANEL_SCRATCH_ARRAYS * (size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
-        GBA_OK(next.alloc(24));
-        GBA_HIP(hipMemsetAsync(next.p, 0, 24, st));
+        GBA_OK(next.alloc(96));
+        GBA_HIP(hipMemsetAsync(next.p, 0, 96, st));
         auto k = num_panel_kernel<S>;
         const size_t lds = (size_t)NUM_PANEL_SLOTS * (sizeof(ACC) + 4);
         GBA_OK(set_lds(k, lds));
@@ -1657,7 +1712,7 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
                            scratch.as<int64_t>(), next.as<unsigned long long>(), P.Cp, P.Ci, Cx, P.bstart, P.bounds);
         GBA_HIP(hipGetLastError());
         mark(4);
-        GBA_HIP(hipMemcpyAsync(P.panel_stats, next.p, 24, hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipMemcpyAsync(P.panel_stats, next.p, 88, hipMemcpyDeviceToHost, st));
         GBA_HIP(hipStreamSynchronize(st));      // scratch is released on return
     } else if (nb.count[BIN_GLOBAL] > 0) {
         const int64_t nf = (P.cvlen + 63) >> 6, ns = (nf + 63) >> 6;
@@ -1916,6 +1971,13 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         rep->bin_vectors[0] = P.num.count[BIN_WAVE]; rep->bin_vectors[1] = P.num.count[BIN_BLK1];
         rep->bin_vectors[2] = P.num.count[BIN_BLK2]; rep->bin_vectors[3] = P.num.count[BIN_GLOBAL];
         rep->panels = (int64_t)P.panel_stats[1]; rep->panels_redone = (int64_t)P.panel_stats[2];
+#ifdef GBA_PANEL_TICKS
+        if (getenv("GBA_PANEL_PROF"))
+            fprintf(stderr, "[gba] numeric panels %llu; 10 ns ticks summed over workgroups: search %llu (+wait %llu) prefix %llu "
+                    "products %llu (+wait %llu) emit %llu panels %llu kernel %llu\n", P.panel_stats[1], P.panel_stats[3],
+                    P.panel_stats[4], P.panel_stats[5], P.panel_stats[6], P.panel_stats[7], P.panel_stats[8], P.panel_stats[9],
+                    P.panel_stats[10]);
+#endif
         DevBuf bs; GBA_OK(bs.alloc(12 * 8));
         GBA_HIP(hipMemsetAsync(bs.p, 0, 96, st));
         for (int b = 0; b < 4; b++) {
