@@ -849,19 +849,31 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
         C->is_csc = csc;
         return GBA_SUCCESS;
     }
+    // the mask is read in C's orientation (GB_accum_mask transposes M when its format differs from C's,
+    // Source/GB_accum_mask.c:178-200); vectors (one of the dimensions is 1, dense format) share the arrays
+    gba_matrix Mturned;
+    const gba_matrix *Mwb = M;
+    if (M && M->is_csc != C_is_csc) {
+        gba_matrix Mw = *M;
+        if (is_sparse(&Mw) && (Mw.jumbled || Mw.nzombies)) { gba_matrix_free_content(&T); GBA_FAIL(GBA_NOT_IMPLEMENTED, "jumbled mask in the other orientation"); }
+        info = transposed(&Mw, &Mturned, ex.owned);
+        if (info != GBA_SUCCESS) { gba_matrix_free_content(&T); return info; }
+        Mturned.is_csc = C_is_csc;
+        Mwb = &Mturned;
+    }
     if (is_dense_fmt(C)) {
-        info = writeback_dense(k, M, &T);
+        info = writeback_dense(k, Mwb, &T);
         gba_matrix_free_content(&T);
         return info;
     }
     if (is_sparse(C) && is_sparse(&T)) {
-        info = writeback_sparse(k, M, &T);
+        info = writeback_sparse(k, Mwb, &T);
         gba_matrix_free_content(&T);
         return info;
     }
     if (is_sparse(C) && is_dense_fmt(&T)) {
         info = sparse_C_to_bitmap(C, k);
-        if (info == GBA_SUCCESS) info = writeback_dense(k, M, &T);
+        if (info == GBA_SUCCESS) info = writeback_dense(k, Mwb, &T);
         gba_matrix_free_content(&T);
         return info;
     }

@@ -1,0 +1,91 @@
+"""Randomised differential test of the front end: gba_mxm / gba_mxv against the definition
+(oracle.mxm_spec, the restatement of Test/GB_spec_mxm.m) over random shapes, storage formats
+(sparse / bitmap / full, by row / by column) of C, Mask, A and B, descriptors, accumulators
+and semirings.  Values are small integers, so every comparison is exact.  A call the device
+path declines must say so with GrB_NOT_IMPLEMENTED -- any other difference is a bug."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from graphblas_amd import Matrix, Type, GrbError, Info
+from graphblas_amd.binding import NP_TYPES
+from oracle import oracle
+from util import assert_dense_same
+
+pytestmark = pytest.mark.gpu
+
+SEMIRINGS = [
+    ("PLUS_TIMES_FP64", Type.FP64, ["PLUS_FP64", "MIN_FP64", "SECOND_FP64", "TIMES_FP64"]),
+    ("PLUS_TIMES_INT32", Type.INT32, ["PLUS_INT32", "MAX_INT32", "FIRST_INT32", "MINUS_INT32"]),
+    ("MIN_PLUS_FP32", Type.FP32, ["MIN_FP32", "PLUS_FP32"]),
+    ("MAX_MIN_INT64", Type.INT64, ["MAX_INT64", "PLUS_INT64"]),
+    ("LOR_LAND_BOOL", Type.BOOL, ["LOR_BOOL", "LXOR_BOOL"]),
+    ("PLUS_PAIR_INT64", Type.INT64, ["PLUS_INT64"]),
+    ("ANY_PAIR_BOOL", Type.BOOL, ["LOR_BOOL"]),
+    ("MIN_FIRSTJ_INT64", Type.INT64, ["MIN_INT64"]),
+    ("PLUS_SECOND_FP32", Type.FP32, ["PLUS_FP32"]),
+    ("TIMES_PLUS_UINT8", Type.UINT8, ["PLUS_UINT8"]),
+]
+
+
+def _random_matrix(rng, nrows, ncols, t, fmt, by_row, density):
+    dt = NP_TYPES[t]
+    vals = rng.integers(1, 4, (nrows, ncols))
+    pres = rng.random((nrows, ncols)) < density
+    if fmt == "full":
+        return Matrix.dense(vals.astype(dt), by_row=by_row)
+    if fmt == "bitmap":
+        return Matrix.dense(vals.astype(dt), present=pres, by_row=by_row)
+    S = sp.csr_matrix(np.where(pres, vals, 0).astype(np.float64))
+    S.eliminate_zeros()
+    return Matrix.from_scipy(S, type=t, by_row=by_row)
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    sr, t, accums = SEMIRINGS[rng.integers(len(SEMIRINGS))]
+    m, k, n = (int(x) for x in rng.integers(1, 40, 3))
+    vector = rng.random() < 0.3
+    if vector:
+        n = 1
+    a_tran, b_tran = bool(rng.random() < 0.35), bool(rng.random() < 0.35) and not vector
+    fmts = ["sparse", "sparse", "bitmap", "full"]
+    A = _random_matrix(rng, *( (k, m) if a_tran else (m, k) ), t, fmts[rng.integers(4)], bool(rng.random() < 0.5), rng.choice([0.05, 0.3, 0.8]))
+    B = _random_matrix(rng, *( (n, k) if b_tran else (k, n) ), t, fmts[rng.integers(4)] if not vector else ["sparse", "bitmap", "full"][rng.integers(3)],
+                       False if vector else bool(rng.random() < 0.5), rng.choice([0.05, 0.3, 0.8]))
+    zt = Type.BOOL if sr.split("_")[1] in ("EQ", "NE", "GT", "LT", "GE", "LE") else t
+    c_fmt = ["empty", "sparse", "bitmap", "full"][rng.integers(4)]
+    c_by_row = False if vector else bool(rng.random() < 0.5)
+    if c_fmt == "empty":
+        C0 = Matrix.sparse_empty(m, n, zt, by_row=c_by_row)
+    else:
+        C0 = _random_matrix(rng, m, n, zt, c_fmt, c_by_row, 0.3)
+    M = None
+    if rng.random() < 0.6:
+        M = _random_matrix(rng, m, n, Type.INT8, ["sparse", "bitmap", "full"][rng.integers(3)],
+                           False if vector else bool(rng.random() < 0.5), 0.4)
+        M.x = (M.x % 2).astype(np.int8) if M.x is not None else M.x          # valued masks carry zeros too
+    accum = accums[rng.integers(len(accums))] if rng.random() < 0.5 else None
+    desc = ("R" if rng.random() < 0.3 else "") + (("S" if rng.random() < 0.5 else "") + ("C" if rng.random() < 0.4 else "") if M is not None else "") \
+        + ("T0" if a_tran else "") + ("T1" if b_tran else "")
+    return sr, A, B, C0, M, accum, desc, vector
+
+
+@pytest.mark.parametrize("seed", range(160))
+def test_random_call_matches_the_definition(gba, seed):
+    sr, A, B, C0, M, accum, desc, vector = _case(seed)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    dM = M.to_device() if M is not None else None
+    what = f"seed {seed}: {sr} accum={accum} desc='{desc}' A={A.sparsity}/{'c' if A.is_csc else 'r'} B={B.sparsity}/" \
+           f"{'c' if B.is_csc else 'r'} C={C0.sparsity}/{C0.nvals} M={None if M is None else M.sparsity}"
+    try:
+        if vector:
+            gba.mxv(dC, dM, accum, sr, dA, dB, desc)
+        else:
+            gba.mxm(dC, dM, accum, sr, dA, dB, desc)
+    except GrbError as e:
+        assert e.info == Info.NOT_IMPLEMENTED, what + f" -> {e}"
+        pytest.skip(f"declined: {e}")
+    p, v = oracle.mxm_spec(C0, M, accum, sr, A, B, desc)
+    got = dC.to_host()
+    assert_dense_same(got, p, v, exact=True, what=what)          # ANY_PAIR yields 1 everywhere: values are pinned too
