@@ -178,6 +178,7 @@ gba_info saxpy5(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const C
 gba_info saxbit(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
                 const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep);
 gba_info transpose(gba_matrix *AT, const gba_matrix *A);
+gba_info to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owned);   // bitmap/full -> sparse copy
 gba_info matrix_wait(gba_matrix *C);
 
 // stage a host-resident view into device memory (PCIe); owned[] collects the

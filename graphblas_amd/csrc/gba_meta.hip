@@ -556,6 +556,27 @@ struct Exec {
     ~Exec() { for (void *p : owned) gba_free(p); }
 };
 
+// Format combinations no specialised kernel takes (dense A with sparse B, two dense operands under a
+// sparse result, two sparse operands in dot form, ...).  The CPU has a template instance for every
+// combination (Source/Template/GB_AxB_dot2_meta.c, GB_AxB_saxbit_template.c); here the operands are
+// brought to the one form every case can take -- both sparse, A not transposed -- and go through saxpy3,
+// which applies any mask.  Same C; these shapes are rare and not performance paths.
+static gba_info general_saxpy3(gba_matrix *T, const Call &k, const gba_matrix *M, const gba_matrix *A, bool A_is_transposed,
+                               const gba_matrix *B, const Canon &c, Exec &ex) {
+    gba_matrix As, Bs, At;
+    if (is_dense_fmt(A)) { GBA_OK(to_sparse(A, &As, ex.owned)); A = &As; }
+    if (is_dense_fmt(B)) { GBA_OK(to_sparse(B, &Bs, ex.owned)); B = &Bs; }
+    if (!is_sparse(A) || !is_sparse(B)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse operand");
+    if (A_is_transposed) {
+        gba_matrix Aw = *A;
+        if (Aw.nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "operand has zombies");
+        GBA_OK(transpose(&At, &Aw));
+        ex.owned.push_back(At.p); ex.owned.push_back(At.i); ex.owned.push_back(At.x);
+        A = &At;
+    }
+    return saxpy3(T, M, k.Mask_comp, k.Mask_struct, A, B, c, k.AxB_method, k.do_sort, &ex.mask_applied, &ex.rep);
+}
+
 // GB_AxB_dot (Source/GB_AxB_dot.c:47-215): C = A'*B
 static gba_info run_dot(gba_matrix *T, const Call &k, const gba_matrix *C_in, const gba_matrix *M,
                         const gba_matrix *A, const gba_matrix *B, bool flipxy, Exec &ex, bool select_only) {
@@ -563,7 +584,8 @@ static gba_info run_dot(gba_matrix *T, const Call &k, const gba_matrix *C_in, co
     GBA_OK(canonicalize(&k.semiring, flipxy, A->type, B->type, &c));
     const bool C_iso = axb_iso(A, B, k.semiring, flipxy);
     if (C_iso && A->iso && as_if_full(A) && B->iso && as_if_full(B)) ex.rep.method = GBA_METHOD_ISO_FULL;
-    if (dot4_control(C_iso, C_in, M, k.Mask_comp, k) && c.add != GBA_ANY) {
+    if (dot4_control(C_iso, C_in, M, k.Mask_comp, k) && c.add != GBA_ANY &&
+        (select_only || (is_sparse(A) && is_dense_fmt(B)))) {
         ex.rep.method = GBA_METHOD_DOT4;
         if (select_only) { ex.done_in_place = true; return GBA_SUCCESS; }
         gba_info info = dot4(k.C, A, B, c, &ex.rep);
@@ -578,7 +600,8 @@ static gba_info run_dot(gba_matrix *T, const Call &k, const gba_matrix *C_in, co
     ex.rep.method = GBA_METHOD_DOT2;
     ex.mask_applied = (M != nullptr);
     if (select_only) return GBA_SUCCESS;
-    return dot2(T, M, k.Mask_comp, k.Mask_struct, A, B, c, &ex.rep);
+    if (is_sparse(A) && is_dense_fmt(B)) return dot2(T, M, k.Mask_comp, k.Mask_struct, A, B, c, &ex.rep);
+    { const int method = ex.rep.method; gba_info info = general_saxpy3(T, k, M, A, true, B, c, ex); ex.rep.method = method; return info; }
 }
 
 // GB_AxB_saxpy (Source/GB_AxB_saxpy.c:16-259): C = A*B
@@ -611,7 +634,9 @@ static gba_info run_saxpy(gba_matrix *T, const Call &k, const gba_matrix *C_in, 
     if (!bitmap_method) {
         ex.rep.method = GBA_METHOD_SAXPY3;
         if (select_only) { ex.mask_applied = (M != nullptr); return GBA_SUCCESS; }
-        gba_info info = saxpy3(T, M, k.Mask_comp, k.Mask_struct, A, B, c, k.AxB_method, k.do_sort, &ex.mask_applied, &ex.rep);
+        gba_info info = (is_sparse(A) && is_sparse(B))
+            ? saxpy3(T, M, k.Mask_comp, k.Mask_struct, A, B, c, k.AxB_method, k.do_sort, &ex.mask_applied, &ex.rep)
+            : general_saxpy3(T, k, M, A, false, B, c, ex);
         if (info == GBA_NO_VALUE) {
             // mask discarded: redo the analysis without it (Source/GB_AxB_saxpy.c:212-225)
             ex.mask_applied = false;
@@ -623,12 +648,13 @@ static gba_info run_saxpy(gba_matrix *T, const Call &k, const gba_matrix *C_in, 
         ex.rep.method = GBA_METHOD_DOT2;        // dot2 with A not transposed (Source/GB_AxB_saxpy.c:237-245)
         ex.mask_applied = (M != nullptr);
         if (select_only) return GBA_SUCCESS;
-        GBA_FAIL(GBA_NOT_IMPLEMENTED, "bitmap C = dense A * sparse B");
+        { gba_info info = general_saxpy3(T, k, M, A, false, B, c, ex); ex.rep.method = GBA_METHOD_DOT2; return info; }
     }
     ex.rep.method = GBA_METHOD_SAXBIT;
     ex.mask_applied = (M != nullptr);
     if (select_only) return GBA_SUCCESS;
-    return saxbit(T, M, k.Mask_comp, k.Mask_struct, A, B, c, &ex.rep);
+    if ((is_sparse(A) || is_dense_fmt(A)) && is_dense_fmt(B)) return saxbit(T, M, k.Mask_comp, k.Mask_struct, A, B, c, &ex.rep);
+    { gba_info info = general_saxpy3(T, k, M, A, false, B, c, ex); ex.rep.method = GBA_METHOD_SAXBIT; return info; }
 }
 
 // GB_mxm + GB_AxB_meta
@@ -674,7 +700,14 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
         if (!select_only && k.C_replace) {
             if (is_sparse(C)) { C->nvals = 0; if (C->p) GBA_HIP(hipMemsetAsync(C->p, 0, (size_t)(C->nvec + 1) * 8, ctx().stream)); }
             else if (is_bitmap(C)) { C->nvals = 0; GBA_HIP(hipMemsetAsync(C->b, 0, (size_t)(C->vlen * C->vdim), ctx().stream)); }
-            else GBA_FAIL(GBA_NOT_IMPLEMENTED, "clearing a full C");
+            else {
+                // a full C loses every entry: it becomes bitmap with nothing present (GB_clear gives an empty matrix)
+                const int64_t n = C->vlen * C->vdim;
+                void *b = gba_malloc((size_t)(n > 0 ? n : 1));
+                if (!b) GBA_FAIL(GBA_OUT_OF_MEMORY, "clearing a full C");
+                GBA_HIP(hipMemsetAsync(b, 0, (size_t)(n > 0 ? n : 1), ctx().stream));
+                C->b = reinterpret_cast<int8_t *>(b); C->sparsity = GBA_BITMAP; C->nvals = 0;
+            }
         }
         if (report) *report = ex.rep;
         return GBA_SUCCESS;

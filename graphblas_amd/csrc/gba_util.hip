@@ -285,6 +285,83 @@ gba_info matrix_wait(gba_matrix *C) {
     return GBA_SUCCESS;
 }
 
+// -------------------------------------------------------- bitmap/full -> sparse --
+// GB_convert_bitmap_to_sparse / GB_convert_full_to_sparse (Source/GB_convert_bitmap_to_sparse.c,
+// GB_convert_full_to_sparse.c): same orientation, entries in index order.  One wavefront per vector.
+__global__ void __launch_bounds__(256)
+dense_count_kernel(int64_t vlen, int64_t vdim, const int8_t *__restrict__ b, int64_t *__restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; j < vdim; j += stride) {
+        int c = 0;
+        for (int64_t i = lane; i < vlen; i += 64) c += (b[j * vlen + i] != 0);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+        if (lane == 0) cnt[j] = c;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+dense_fill_kernel(int64_t vlen, int64_t vdim, const int8_t *__restrict__ b, const uint8_t *__restrict__ x, bool iso,
+                  int esize, const int64_t *__restrict__ Sp, int64_t *__restrict__ Si, uint8_t *__restrict__ Sx) {
+    const int lane = threadIdx.x & 63;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; j < vdim; j += stride) {
+        int64_t out = Sp[j];
+        for (int64_t base = 0; base < vlen; base += 64) {
+            const int64_t i = base + lane;
+            const bool live = (i < vlen) && (!b || b[j * vlen + i] != 0);
+            const unsigned long long m = __ballot(live);
+            if (live) {
+                const int64_t q = out + __builtin_popcountll(m & ((1ull << lane) - 1));
+                Si[q] = i;
+                if (!iso) for (int t = 0; t < esize; t++) Sx[q * esize + t] = x[(j * vlen + i) * esize + t];
+            }
+            out += __builtin_popcountll(m);
+        }
+    }
+}
+
+gba_info to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owned) {
+    GBA_OK(require_init());
+    if (!is_bitmap(X) && !is_full(X)) GBA_FAIL(GBA_INVALID_VALUE, "to_sparse: sparsity %d", X->sparsity);
+    hipStream_t st = ctx().stream;
+    const int64_t vlen = X->vlen, vdim = X->vdim;
+    const int esize = (int)type_size(X->type);
+    DevBuf Sp, Si, Sx;
+    GBA_OK(Sp.alloc((size_t)(vdim + 1) * 8));
+    GBA_HIP(hipMemsetAsync(Sp.p, 0, (size_t)(vdim + 1) * 8, st));
+    int64_t blocks = ceil_div(vdim * 64, 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    int64_t nnz = vlen * vdim;
+    if (is_bitmap(X)) {
+        if (vdim > 0) hipLaunchKernelGGL(dense_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, vlen, vdim, X->b, Sp.as<int64_t>());
+        GBA_OK(dev_cumsum_i64(Sp.as<int64_t>(), vdim, st));
+        GBA_OK(dev_read_i64(Sp.as<int64_t>() + vdim, &nnz));
+    } else {
+        std::vector<int64_t> hp((size_t)vdim + 1);
+        for (int64_t j = 0; j <= vdim; j++) hp[(size_t)j] = j * vlen;
+        GBA_HIP(hipMemcpyAsync(Sp.p, hp.data(), (size_t)(vdim + 1) * 8, hipMemcpyHostToDevice, st));
+        GBA_HIP(hipStreamSynchronize(st));
+    }
+    GBA_OK(Si.alloc((size_t)(nnz > 0 ? nnz : 1) * 8));
+    GBA_OK(Sx.alloc((size_t)((X->iso || nnz == 0) ? 1 : nnz) * (esize > 0 ? esize : 1)));
+    if (X->iso && X->x && esize > 0) GBA_HIP(hipMemcpyAsync(Sx.p, X->x, (size_t)esize, hipMemcpyDeviceToDevice, st));
+    if (vdim > 0 && nnz > 0) {
+        hipLaunchKernelGGL(dense_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, vlen, vdim, is_bitmap(X) ? X->b : nullptr,
+                           reinterpret_cast<const uint8_t *>(X->x), X->iso, esize, Sp.as<int64_t>(), Si.as<int64_t>(), Sx.as<uint8_t>());
+        GBA_HIP(hipGetLastError());
+    }
+    GBA_HIP(hipStreamSynchronize(st));
+    *S = *X;
+    S->p = reinterpret_cast<int64_t *>(Sp.release()); S->i = reinterpret_cast<int64_t *>(Si.release()); S->x = Sx.release();
+    S->b = nullptr; S->h = nullptr;
+    S->nvec = vdim; S->nvals = nnz; S->sparsity = GBA_SPARSE; S->jumbled = false; S->nzombies = 0; S->mem = GBA_MEM_DEVICE;
+    owned.push_back(S->p); owned.push_back(S->i); owned.push_back(S->x);
+    return GBA_SUCCESS;
+}
+
 // --------------------------------------------------------------- transpose --
 __global__ void __launch_bounds__(256)
 transpose_count_kernel(int64_t anz, const int64_t *__restrict__ Ai, unsigned long long *__restrict__ cnt) {
