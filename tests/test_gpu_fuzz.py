@@ -41,10 +41,10 @@ def _random_matrix(rng, nrows, ncols, t, fmt, by_row, density):
     return Matrix.from_scipy(S, type=t, by_row=by_row)
 
 
-def _case(seed):
+def _case(seed, lo=1, hi=40):
     rng = np.random.default_rng(1000 + seed)
     sr, t, accums = SEMIRINGS[rng.integers(len(SEMIRINGS))]
-    m, k, n = (int(x) for x in rng.integers(1, 40, 3))
+    m, k, n = (int(x) for x in rng.integers(lo, hi, 3))
     vector = rng.random() < 0.3
     if vector:
         n = 1
@@ -73,7 +73,16 @@ def _case(seed):
 
 @pytest.mark.parametrize("seed", range(160))
 def test_random_call_matches_the_definition(gba, seed):
-    sr, A, B, C0, M, accum, desc, vector = _case(seed)
+    _check(gba, seed, *_case(seed))
+
+
+@pytest.mark.parametrize("seed", range(500, 548))
+def test_random_call_matches_the_definition_larger(gba, seed):
+    """Dimensions of 120..320: vectors reach the block-level hash kernels and the long-row dot paths."""
+    _check(gba, seed, *_case(seed, 120, 320))
+
+
+def _check(gba, seed, sr, A, B, C0, M, accum, desc, vector):
     dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
     dM = M.to_device() if M is not None else None
     what = f"seed {seed}: {sr} accum={accum} desc='{desc}' A={A.sparsity}/{'c' if A.is_csc else 'r'} B={B.sparsity}/" \
