@@ -9,11 +9,11 @@ fallback: importing the bindings without the built library raises.
 """
 from .binding import (  # noqa: F401
     lib, GrbError, Info, Type, Op, Sparsity, Desc, Method,
-    gba_matrix, gba_semiring, gba_binop, gba_descriptor, gba_report,
+    gba_matrix, gba_semiring, gba_binop, gba_descriptor, gba_report, gba_user_semiring,
     semiring, binop, descriptor, init, finalize, NP_TYPES, TYPE_OF_NP,
 )
 from .host import (  # noqa: F401
-    Matrix, DeviceMatrix, mxm, mxv, vxm, mxm_select,
+    Matrix, DeviceMatrix, mxm, mxv, vxm, mxm_select, mxm_udt, register_udt, user_semiring,
     AxB_saxpy3, AxB_saxpy3_flopcount, AxB_dot3, AxB_dot2, AxB_dot4, AxB_saxpy4, AxB_saxpy5, AxB_saxbit,
     cumsum, matrix_wait, transpose, partition_by_flops, sync, timer_start, timer_stop,
 )

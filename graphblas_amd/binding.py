@@ -108,6 +108,11 @@ class gba_report(C.Structure):
                 ("panels", C.c_int64), ("panels_redone", C.c_int64), ("cnz", C.c_int64)]
 
 
+class gba_user_semiring(C.Structure):
+    _fields_ = [("type_name", C.c_char_p), ("type_defn", C.c_char_p), ("type_size", C.c_size_t),
+                ("add_name", C.c_char_p), ("add_defn", C.c_char_p), ("mult_name", C.c_char_p), ("mult_defn", C.c_char_p)]
+
+
 class GrbError(RuntimeError):
     def __init__(self, info, msg):
         super().__init__(f"{Info.name(info)} ({info}): {msg}")
@@ -195,6 +200,7 @@ class _Lib:
             "gba_mxv": (i32, [M, M, B, S, M, M, D, R]),
             "gba_vxm": (i32, [M, M, B, S, M, M, D, R]),
             "gba_mxm_select": (i32, [M, M, B, S, M, M, D, R]),
+            "gba_mxm_udt": (i32, [M, M, C.c_char_p, C.c_char_p, P(gba_user_semiring), M, M, D, R]),
             "gba_AxB_saxpy3": (i32, [M, M, b, b, M, M, S, i32, i32, P(b), R]),
             "gba_AxB_saxpy3_flopcount": (i32, [P(i64), vp, M, b, M, M]),
             "gba_AxB_dot3": (i32, [M, M, b, M, M, S, R]),

@@ -23,6 +23,7 @@ void set_error(const char *fmt, ...);
 
 // ----------------------------------------------------------------- context --
 struct Context {
+    size_t udt_size = 0;            // element size of GBA_UDT matrices while a user-defined call is running
     bool inited = false;
     int device = -1;
     hipStream_t stream = nullptr;
@@ -31,6 +32,8 @@ struct Context {
 };
 Context &ctx();
 gba_info require_init();
+// bytes per entry of a matrix, user-defined types included
+inline size_t esize_of(int type) { return type == GBA_UDT ? ctx().udt_size : type_size(type); }
 
 // RAII device buffer (freed with gba_free unless released)
 struct DevBuf {

@@ -1,0 +1,255 @@
+// User-defined types and operators: C<M> = accum (C, A*B) over a semiring given as C source, the way
+// GxB_Type_new / GxB_BinaryOp_new hand their definitions to the reference's JIT
+// (Include/GraphBLAS.h: GxB_Type_new, GxB_BinaryOp_new; Source/GB_jitifyer.c compiles them with the C
+// compiler and dlopens the result).  Here hipRTC compiles them for the device that is current and the
+// code object is kept per source text.
+//
+// The pattern of T = A*B does not depend on the types, so it comes from the existing pattern-only
+// kernels (saxpy3 with ANY_PAIR).  The values are then one dot product per entry of T -- the rows of A
+// against the columns of B, both sorted, merged by one thread in increasing k, with the user's multiply
+// and add called in the order the CPU's dot kernels use (Source/Template/GB_AxB_dot_cij.c).  No atomics
+// are needed, so any type size works.
+#include "gba_internal.hpp"
+#include <hip/hiprtc.h>
+#include <map>
+#include <mutex>
+#include <string>
+
+namespace gba {
+
+struct JitKernels { hipModule_t module = nullptr; hipFunction_t dot = nullptr, accum = nullptr; };
+
+static std::mutex g_jit_mu;
+static std::map<std::string, JitKernels> g_jit_cache;
+
+#define GBA_RTC(call) do { hiprtcResult r_ = (call); if (r_ != HIPRTC_SUCCESS) \
+    GBA_FAIL(GBA_PANIC, "%s -> %s", #call, hiprtcGetErrorString(r_)); } while (0)
+
+static std::string device_function(const char *defn) {
+    // "void f (T *z, const T *x, const T *y) { ... }"  ->  a __device__ function
+    return std::string("__device__ inline ") + defn + "\n";
+}
+
+static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, const char *accum_defn, JitKernels *out) {
+    std::string src;
+    src += "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
+           "typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;\n";
+    src += std::string(s->type_defn) + "\n";
+    src += device_function(s->add_defn);
+    if (std::string(s->mult_defn) != s->add_defn) src += device_function(s->mult_defn);
+    const bool own_accum = accum_defn && std::string(accum_defn) != s->add_defn && std::string(accum_defn) != s->mult_defn;
+    if (own_accum) src += device_function(accum_defn);
+    const std::string T = s->type_name, ADD = s->add_name, MULT = s->mult_name, ACC = accum_name ? accum_name : s->add_name;
+    src +=
+        "extern \"C\" __global__ void gba_udt_dot (int64_t nvec, int64_t tnz, const int64_t *Tp, const int64_t *Ti, " + T + " *Tx,\n"
+        "    const int64_t *Ap, const int64_t *Ai, const " + T + " *Ax, int A_iso,\n"
+        "    const int64_t *Bp, const int64_t *Bi, const " + T + " *Bx, int B_iso)\n"
+        "{\n"
+        "    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x ;\n"
+        "    if (p >= tnz) return ;\n"
+        "    int64_t lo = 0, hi = nvec - 1 ;                 // vector j of T that holds entry p\n"
+        "    while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1 ; if (Tp [mid] <= p) lo = mid ; else hi = mid - 1 ; }\n"
+        "    const int64_t j = lo, i = Ti [p] ;\n"
+        "    int64_t pa = Ap [i], pa1 = Ap [i+1], pb = Bp [j], pb1 = Bp [j+1] ;\n"
+        "    " + T + " z ; int first = 1 ;\n"
+        "    while (pa < pa1 && pb < pb1)\n"
+        "    {\n"
+        "        const int64_t ka = Ai [pa], kb = Bi [pb] ;\n"
+        "        if (ka < kb) pa++ ; else if (kb < ka) pb++ ;\n"
+        "        else\n"
+        "        {\n"
+        "            " + T + " t ;\n"
+        "            " + MULT + " (&t, &Ax [A_iso ? 0 : pa], &Bx [B_iso ? 0 : pb]) ;\n"
+        "            if (first) { z = t ; first = 0 ; } else " + ADD + " (&z, &z, &t) ;\n"
+        "            pa++ ; pb++ ;\n"
+        "        }\n"
+        "    }\n"
+        "    Tx [p] = z ;\n"
+        "}\n"
+        "extern \"C\" __global__ void gba_udt_accum (int64_t nvec, int64_t tnz, const int64_t *Tp, const int64_t *Ti, const " + T + " *Tx,\n"
+        "    " + T + " *Cx, int8_t *Cb, int64_t stride_i, int64_t stride_j)\n"
+        "{\n"
+        "    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x ;\n"
+        "    if (p >= tnz) return ;\n"
+        "    int64_t lo = 0, hi = nvec - 1 ;\n"
+        "    while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1 ; if (Tp [mid] <= p) lo = mid ; else hi = mid - 1 ; }\n"
+        "    const int64_t pos = Ti [p] * stride_i + lo * stride_j ;\n"
+        "    if (!Cb || Cb [pos]) " + ACC + " (&Cx [pos], &Cx [pos], &Tx [p]) ;\n"
+        "    else { Cx [pos] = Tx [p] ; Cb [pos] = 1 ; }\n"
+        "}\n";
+
+    std::lock_guard<std::mutex> lock(g_jit_mu);
+    auto it = g_jit_cache.find(src);
+    if (it != g_jit_cache.end()) { *out = it->second; return GBA_SUCCESS; }
+
+    hiprtcProgram prog;
+    GBA_RTC(hiprtcCreateProgram(&prog, src.c_str(), "gba_udt.hip", 0, nullptr, nullptr));
+    hipDeviceProp_t prop;
+    GBA_HIP(hipGetDeviceProperties(&prop, ctx().device));
+    const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+    const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off"};
+    const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
+    if (cr != HIPRTC_SUCCESS) {
+        size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        GBA_FAIL(GBA_INVALID_VALUE, "the user-defined semiring does not compile: %.600s", log.c_str());
+    }
+    size_t csize = 0;
+    GBA_RTC(hiprtcGetCodeSize(prog, &csize));
+    std::string code(csize, '\0');
+    GBA_RTC(hiprtcGetCode(prog, &code[0]));
+    hiprtcDestroyProgram(&prog);
+    JitKernels k;
+    GBA_HIP(hipModuleLoadData(&k.module, code.data()));
+    GBA_HIP(hipModuleGetFunction(&k.dot, k.module, "gba_udt_dot"));
+    GBA_HIP(hipModuleGetFunction(&k.accum, k.module, "gba_udt_accum"));
+    g_jit_cache[src] = k;
+    *out = k;
+    return GBA_SUCCESS;
+}
+
+// the operand as a sparse matrix whose vectors are the rows (want_rows) or the columns of op(X)
+static gba_info sparse_lists(const gba_matrix *X, bool tran, bool want_rows, gba_matrix *out, std::vector<void *> &owned) {
+    gba_matrix S = *X;
+    if (is_hyper(X)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse operand");
+    if (X->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "operand has zombies");
+    if (is_dense_fmt(X)) GBA_OK(to_sparse(X, &S, owned));
+    // vectors of S are rows of X when X is held by row; op(X) = X' swaps rows and columns
+    const bool vectors_are_rows = (!S.is_csc) != tran;
+    if (vectors_are_rows == want_rows) {
+        if (S.jumbled) GBA_FAIL(GBA_NOT_IMPLEMENTED, "jumbled operand (wait on it first)");
+        *out = S;
+        return GBA_SUCCESS;
+    }
+    gba_matrix Tm;
+    GBA_OK(transpose(&Tm, &S));
+    owned.push_back(Tm.p); owned.push_back(Tm.i); owned.push_back(Tm.x);
+    *out = Tm;
+    return GBA_SUCCESS;
+}
+
+static gba_matrix pattern_view(const gba_matrix &S) {
+    gba_matrix v = S;
+    v.type = GBA_BOOL; v.iso = true;        // ANY_PAIR reads no values
+    return v;
+}
+
+gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
+                 const gba_user_semiring *s, const gba_matrix *A, const gba_matrix *B, const gba_descriptor *desc,
+                 gba_report *report) {
+    GBA_OK(require_init());
+    if (!C || !s || !A || !B) GBA_FAIL(GBA_NULL_POINTER, "gba_mxm_udt: null argument");
+    if (!s->type_name || !s->type_defn || !s->add_name || !s->add_defn || !s->mult_name || !s->mult_defn || s->type_size == 0)
+        GBA_FAIL(GBA_NULL_POINTER, "gba_mxm_udt: the semiring needs type and operator names and definitions");
+    if (A->type != GBA_UDT || B->type != GBA_UDT || C->type != GBA_UDT)
+        GBA_FAIL(GBA_DOMAIN_MISMATCH, "gba_mxm_udt: A, B and C must have the user-defined type");
+    if (C->mem != GBA_MEM_DEVICE || A->mem != GBA_MEM_DEVICE || B->mem != GBA_MEM_DEVICE || (M && M->mem != GBA_MEM_DEVICE))
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "gba_mxm_udt: device views only");
+    const bool A_tran = desc && desc->in0 == GBA_TRAN, B_tran = desc && desc->in1 == GBA_TRAN;
+    const bool C_replace = desc && desc->out == GBA_REPLACE;
+    const bool Mask_comp = desc && (desc->mask == GBA_COMP || desc->mask == GBA_COMP_STRUCTURE);
+    const bool Mask_struct = desc && (desc->mask == GBA_STRUCTURE || desc->mask == GBA_COMP_STRUCTURE);
+    auto rows = [](const gba_matrix *X) { return X->is_csc ? X->vlen : X->vdim; };
+    auto cols = [](const gba_matrix *X) { return X->is_csc ? X->vdim : X->vlen; };
+    const int64_t m = A_tran ? cols(A) : rows(A), ka = A_tran ? rows(A) : cols(A);
+    const int64_t kb = B_tran ? cols(B) : rows(B), n = B_tran ? rows(B) : cols(B);
+    if (ka != kb || rows(C) != m || cols(C) != n) GBA_FAIL(GBA_DIMENSION_MISMATCH, "gba_mxm_udt: %ld-by-%ld times %ld-by-%ld into %ld-by-%ld",
+                                                          (long)m, (long)ka, (long)kb, (long)n, (long)rows(C), (long)cols(C));
+    if (M && (rows(M) != m || cols(M) != n)) GBA_FAIL(GBA_DIMENSION_MISMATCH, "gba_mxm_udt: mask dimensions");
+    if (!M && Mask_comp) GBA_FAIL(GBA_NOT_IMPLEMENTED, "gba_mxm_udt: complemented empty mask");
+    hipStream_t st = ctx().stream;
+    struct SizeScope { size_t old; SizeScope(size_t v) : old(ctx().udt_size) { ctx().udt_size = v; } ~SizeScope() { ctx().udt_size = old; } }
+        scope(s->type_size);
+    gba_report rep{};
+    KernelTimer timer(report != nullptr);
+
+    JitKernels jit;
+    GBA_OK(jit_build(s, accum_name, accum_defn, &jit));
+
+    struct Owned { std::vector<void *> v; ~Owned() { for (void *p : v) gba_free(p); } } own;
+    gba_matrix Arows, Acols, Bcols, Mcol;
+    GBA_OK(sparse_lists(A, A_tran, true, &Arows, own.v));
+    GBA_OK(sparse_lists(A, A_tran, false, &Acols, own.v));
+    GBA_OK(sparse_lists(B, B_tran, false, &Bcols, own.v));
+    const gba_matrix *Mc = nullptr;
+    if (M) {
+        if (is_hyper(M)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse mask");
+        Mcol = *M;
+        if (!M->is_csc) {                                  // the pattern pass works by column
+            if (is_sparse(M)) { GBA_OK(transpose(&Mcol, M)); own.v.push_back(Mcol.p); own.v.push_back(Mcol.i); own.v.push_back(Mcol.x); }
+            else GBA_FAIL(GBA_NOT_IMPLEMENTED, "gba_mxm_udt: bitmap/full mask held by row");
+        }
+        Mcol.is_csc = true;
+        Mc = &Mcol;
+    }
+
+    // pattern of T = op(A)*op(B), by column
+    gba_semiring anypair{GBA_ANY, GBA_PAIR, GBA_BOOL, GBA_BOOL, GBA_BOOL};
+    Canon c;
+    GBA_OK(canonicalize(&anypair, false, GBA_BOOL, GBA_BOOL, &c));
+    gba_matrix Ap_ = pattern_view(Acols), Bp_ = pattern_view(Bcols), T{};
+    Ap_.is_csc = Bp_.is_csc = true;
+    bool applied = false;
+    GBA_OK(saxpy3(&T, Mc, Mask_comp, Mask_struct, &Ap_, &Bp_, c, 0, 0, &applied, nullptr));
+    const int64_t tnz = T.nvals;
+    gba_free(T.x); T.x = nullptr;                          // the boolean values are not wanted
+    void *Tx = gba_malloc((size_t)(tnz > 0 ? tnz : 1) * s->type_size);
+    if (!Tx) { gba_matrix_free_content(&T); GBA_FAIL(GBA_OUT_OF_MEMORY, "gba_mxm_udt: values of T"); }
+    T.x = Tx; T.type = GBA_UDT; T.iso = false; T.is_csc = true;
+    if (tnz > 0) {
+        int64_t nvec = T.nvec; int a_iso = Arows.iso, b_iso = Bcols.iso;
+        void *args[] = {&nvec, (void *)&tnz, &T.p, &T.i, &T.x, &Arows.p, &Arows.i, &Arows.x, &a_iso, &Bcols.p, &Bcols.i, &Bcols.x, &b_iso};
+        const hipError_t e = hipModuleLaunchKernel(jit.dot, (unsigned)ceil_div(tnz, 256), 1, 1, 256, 1, 1, 0, st, args, nullptr);
+        if (e != hipSuccess) { gba_matrix_free_content(&T); GBA_FAIL(GBA_PANIC, "launch of the compiled dot kernel: %s", hipGetErrorString(e)); }
+    }
+    GBA_HIP(hipStreamSynchronize(st));
+    rep.method = GBA_METHOD_DOT3; rep.mask_applied = (M != nullptr); rep.cnz = tnz;
+
+    // C<M> = accum (C,T)
+    const bool has_accum = accum_name != nullptr;
+    const bool c_empty = is_sparse(C) && C->nvals == 0;
+    gba_info info = GBA_SUCCESS;
+    if (!has_accum && (c_empty || C_replace || !M)) {
+        // no mask: C = T.  masked: T already holds only permitted entries, and C is empty or replaced
+        if (!C->is_csc) {
+            gba_matrix Tr;
+            info = transpose(&Tr, &T);
+            gba_matrix_free_content(&T);
+            if (info != GBA_SUCCESS) return info;
+            T = Tr;
+        }
+        const bool keep_csc = C->is_csc;
+        // the old arrays of C belong to the caller's handle; when C is also an input they were read above
+        gba_matrix_free_content(C);
+        *C = T;
+        C->is_csc = keep_csc; C->type = GBA_UDT; C->mem = GBA_MEM_DEVICE;
+    } else if (has_accum && !M && is_dense_fmt(C) && !C->iso) {
+        if (tnz > 0) {
+            int64_t nvec = T.nvec;
+            // T is by column: vector j = column, index i = row; C(i,j) sits at i*stride_i + j*stride_j
+            int64_t stride_i = C->is_csc ? 1 : C->vlen, stride_j = C->is_csc ? C->vlen : 1;
+            int8_t *Cb = is_bitmap(C) ? C->b : nullptr;
+            void *args[] = {&nvec, (void *)&tnz, &T.p, &T.i, &T.x, &C->x, &Cb, &stride_i, &stride_j};
+            const hipError_t e = hipModuleLaunchKernel(jit.accum, (unsigned)ceil_div(tnz, 256), 1, 1, 256, 1, 1, 0, st, args, nullptr);
+            if (e != hipSuccess) info = GBA_PANIC;
+            GBA_HIP(hipStreamSynchronize(st));
+            if (is_bitmap(C)) { int64_t nv = 0; if (dev_count_ones(C->b, C->vlen * C->vdim, &nv) == GBA_SUCCESS) C->nvals = nv; }
+        }
+        gba_matrix_free_content(&T);
+        rep.done_in_place = 1;
+    } else {
+        gba_matrix_free_content(&T);
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "gba_mxm_udt: this combination of accum, mask and C format");
+    }
+    if (report) { rep.kernel_ms = timer.stop_ms(); *report = rep; }
+    return info;
+}
+
+}  // namespace gba
+
+extern "C" gba_info gba_mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
+                                const gba_user_semiring *semiring, const gba_matrix *A, const gba_matrix *B,
+                                const gba_descriptor *desc, gba_report *report) {
+    return gba::mxm_udt(C, M, accum_name, accum_defn, semiring, A, B, desc, report);
+}

@@ -172,7 +172,7 @@ static gba_info dense_transposed(const gba_matrix *A, gba_matrix *AT, std::vecto
     if (A->vlen == 1 || A->vdim == 1) return GBA_SUCCESS;
     hipStream_t st = ctx().stream;
     const int64_t n = A->vlen * A->vdim;
-    const int esize = (int)type_size(A->type);
+    const int esize = (int)esize_of(A->type);
     if (A->b) {
         void *b = gba_malloc((size_t)n); if (!b) GBA_FAIL(GBA_OUT_OF_MEMORY, "dense transpose");
         owned.push_back(b);

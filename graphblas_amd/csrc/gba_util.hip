@@ -123,7 +123,7 @@ sort_vectors_lds_kernel(int64_t nlist, const int64_t *__restrict__ list, const i
 
 // classify vectors: 0 already sorted / short, 1 LDS sort, 2 too long for LDS
 __global__ void __launch_bounds__(256)
-classify_sort_kernel(int64_t nvec, const int64_t *__restrict__ Cp, const int64_t *__restrict__ Ci,
+classify_sort_kernel(int64_t nvec, const int64_t *__restrict__ Cp, const int64_t *__restrict__ Ci, int lds_max,
                      unsigned int *__restrict__ counters, int64_t *__restrict__ lds_list, int64_t *__restrict__ big_list) {
     const int lane = threadIdx.x & 63;
     int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -134,7 +134,7 @@ classify_sort_kernel(int64_t nvec, const int64_t *__restrict__ Cp, const int64_t
         for (int64_t p = p0 + 1 + lane; p < p1; p += 64) bad |= (Ci[p - 1] > Ci[p]);
         bad = __any(bad);
         if (bad && lane == 0) {
-            if (p1 - p0 <= SORT_MAX) { unsigned int q = atomicAdd(&counters[0], 1u); lds_list[q] = j; }
+            if (p1 - p0 <= lds_max) { unsigned int q = atomicAdd(&counters[0], 1u); lds_list[q] = j; }
             else { unsigned int q = atomicAdd(&counters[1], 1u); big_list[q] = j; }
         }
     }
@@ -234,7 +234,7 @@ gba_info matrix_wait(gba_matrix *C) {
     if (C->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_NOT_IMPLEMENTED, "wait on a host view");
     hipStream_t st = ctx().stream;
     const int64_t nvec = C->nvec;
-    const int esize = (int)type_size(C->type);
+    const int esize = (int)esize_of(C->type);
     if (C->iso) GBA_FAIL(GBA_NOT_IMPLEMENTED, "wait on an iso matrix");
     int64_t wblocks = ceil_div(nvec * 64, 256); if (wblocks > 8192) wblocks = 8192; if (wblocks < 1) wblocks = 1;
     if (C->nzombies > 0) {
@@ -265,6 +265,7 @@ gba_info matrix_wait(gba_matrix *C) {
         GBA_OK(big_list.alloc((size_t)(nvec > 0 ? nvec : 1) * 8));
         GBA_HIP(hipMemsetAsync(counters.p, 0, 8, st));
         hipLaunchKernelGGL(classify_sort_kernel, dim3((unsigned)wblocks), dim3(256), 0, st, nvec, C->p, C->i,
+                           esize <= 8 ? SORT_MAX : 0,      // the LDS sort stages values of up to 8 bytes
                            counters.as<unsigned int>(), lds_list.as<int64_t>(), big_list.as<int64_t>());
         unsigned int h[2] = {0, 0};
         GBA_HIP(hipMemcpyAsync(h, counters.p, 8, hipMemcpyDeviceToHost, st));
@@ -329,7 +330,7 @@ gba_info to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owne
     if (!is_bitmap(X) && !is_full(X)) GBA_FAIL(GBA_INVALID_VALUE, "to_sparse: sparsity %d", X->sparsity);
     hipStream_t st = ctx().stream;
     const int64_t vlen = X->vlen, vdim = X->vdim;
-    const int esize = (int)type_size(X->type);
+    const int esize = (int)esize_of(X->type);
     DevBuf Sp, Si, Sx;
     GBA_OK(Sp.alloc((size_t)(vdim + 1) * 8));
     GBA_HIP(hipMemsetAsync(Sp.p, 0, (size_t)(vdim + 1) * 8, st));
@@ -395,7 +396,7 @@ gba_info transpose(gba_matrix *AT, const gba_matrix *A) {
     if (A->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_NOT_IMPLEMENTED, "transpose of a host view");
     hipStream_t st = ctx().stream;
     const int64_t anz = A->nvals, tvec = A->vlen, avec = A->nvec;
-    const int esize = (int)type_size(A->type);
+    const int esize = (int)esize_of(A->type);
     DevBuf Tp, Ti, Tx, cur;
     GBA_OK(Tp.alloc((size_t)(tvec + 1) * 8));
     GBA_OK(cur.alloc((size_t)(tvec + 1) * 8));

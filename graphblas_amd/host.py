@@ -10,7 +10,7 @@ argument order: mxm(C, Mask, accum, semiring, A, B, desc).
 import ctypes as C
 import numpy as np
 
-from .binding import (lib, Type, Sparsity, NP_TYPES, TYPE_OF_NP, gba_matrix, gba_report, gba_semiring,
+from .binding import (lib, Type, Sparsity, NP_TYPES, TYPE_OF_NP, gba_matrix, gba_report, gba_semiring, gba_user_semiring,
                       gba_binop, gba_descriptor, semiring as _semiring, binop as _binop, descriptor as _descriptor)
 
 MEM_DEVICE, MEM_HOST = 0, 1
@@ -263,6 +263,32 @@ def mxv(w, mask, accum, semiring, A, u, desc=None):
 def vxm(w, mask, accum, semiring, u, A, desc=None):
     """w'<mask'> = accum (w', u'*A) -- GrB_vxm (Include/GraphBLAS.h:4651-4660)."""
     return _call3(lib.gba_vxm, w, mask, accum, semiring, u, A, desc)
+
+
+def register_udt(dtype):
+    """numpy dtype that host copies of GBA_UDT matrices use (one user-defined type at a time)."""
+    dt = np.dtype(dtype)
+    NP_TYPES[Type.UDT] = dt
+    TYPE_OF_NP[dt] = Type.UDT
+    return dt
+
+
+def user_semiring(type_name, type_defn, type_size, add_name, add_defn, mult_name, mult_defn):
+    s = gba_user_semiring()
+    s.type_name, s.type_defn, s.type_size = type_name.encode(), type_defn.encode(), type_size
+    s.add_name, s.add_defn = add_name.encode(), add_defn.encode()
+    s.mult_name, s.mult_defn = mult_name.encode(), mult_defn.encode()
+    return s
+
+
+def mxm_udt(C_, Mask, accum, semiring, A, B, desc=None):
+    """C<Mask> = accum (C, A*B) over a user-defined semiring; accum is None or (name, defn)."""
+    rep = gba_report()
+    d = _desc(desc)
+    an, ad = (accum[0].encode(), accum[1].encode()) if accum else (None, None)
+    lib.check(lib.gba_mxm_udt(C_.ref(), _ref(Mask), an, ad, C.byref(semiring), A.ref(), B.ref(),
+                              C.byref(d) if d is not None else None, C.byref(rep)))
+    return rep
 
 
 def mxm_select(C_, Mask, accum, semiring, A, B, desc=None):

@@ -229,6 +229,30 @@ gba_info gba_mxm(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
                  const gba_semiring *semiring, const gba_matrix *A, const gba_matrix *B,
                  const gba_descriptor *desc, gba_report *report);
 
+/* User-defined type and operators, given as C source exactly as to GxB_Type_new and GxB_BinaryOp_new
+ * (Include/GraphBLAS.h, "GxB_Type_new (&type, sizeof (ctype), name, defn)" and "GxB_BinaryOp_new (&op, f,
+ * ztype, xtype, ytype, name, defn)"; the reference's JIT compiles the same strings with the C compiler,
+ * Source/GB_jitifyer.c).  hipRTC compiles them for the current device; code objects are cached per source.
+ * One type serves x, y and z (the shape of Demo/Program/gauss_demo.c:300-360). */
+typedef struct {
+    const char *type_name;      /* "gauss" */
+    const char *type_defn;      /* "typedef struct { int32_t real ; int32_t imag ; } gauss ;" */
+    size_t      type_size;      /* sizeof (gauss) */
+    const char *add_name;       /* "addgauss" */
+    const char *add_defn;       /* "void addgauss (gauss *z, const gauss *x, const gauss *y) { ... }" */
+    const char *mult_name;
+    const char *mult_defn;
+} gba_user_semiring;
+
+/* C<M> = accum (C, A*B) over a user-defined semiring: GrB_mxm for matrices of type GBA_UDT
+ * (Source/GB_mxm.c:24).  accum_name/accum_defn NULL = no accumulator.  C may be the same handle as A or
+ * B (A = A*A), not a copy of it.  Taken: every format and orientation of A and B; M sparse (any
+ * orientation) or bitmap/full held by column; C empty, replaced, or unmasked without accum (C = T), and
+ * C bitmap/full with accum and no mask (in place).  Anything else: GBA_NOT_IMPLEMENTED. */
+gba_info gba_mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
+                     const gba_user_semiring *semiring, const gba_matrix *A, const gba_matrix *B,
+                     const gba_descriptor *desc, gba_report *report);
+
 /* w<mask> = accum (w, A*u)   -- GrB_mxv (Include/GraphBLAS.h:4662-4671, Source/GrB_mxv.c:18) */
 gba_info gba_mxv(gba_matrix *w, const gba_matrix *mask, const gba_binop *accum,
                  const gba_semiring *semiring, const gba_matrix *A, const gba_matrix *u,

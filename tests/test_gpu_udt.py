@@ -1,0 +1,112 @@
+"""User-defined type and semiring, compiled at run time: the seven GrB_mxm calls of
+Demo/Program/gauss_demo.c:402-470 replayed through gba_mxm_udt on the device and compared with
+the reference's own printed results (Demo/Output/gauss_demo.out, fixture
+tests/golden/gauss_demo_mxm.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import graphblas_amd as g
+from graphblas_amd import Matrix, Type, Sparsity
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "gauss_demo_mxm.json")
+
+# a Gaussian integer, its sum and its product: what the application hands to GxB_Type_new /
+# GxB_BinaryOp_new as strings (Demo/Program/gauss_demo.c:22-26, 60-66, 88-96 declare the same type
+# and operators)
+GAUSS_DEFN = "typedef struct { int32_t real ; int32_t imag ; } gauss ;"
+ADD_DEFN = """void addgauss (gauss *z, const gauss *x, const gauss *y)
+{
+    z->real = x->real + y->real ;
+    z->imag = x->imag + y->imag ;
+}"""
+MULT_DEFN = """void multgauss (gauss *z, const gauss *x, const gauss *y)
+{
+    int32_t zr = x->real * y->real - x->imag * y->imag ;
+    int32_t zi = x->real * y->imag + x->imag * y->real ;
+    z->real = zr ;
+    z->imag = zi ;
+}"""
+
+
+def _gauss_matrix(dt, entries, by_row=True):
+    """entries: dict (i,j) -> (real, imag); a 4-by-4 sparse matrix held by row."""
+    keys = sorted(entries)
+    rows = np.array([k[0] for k in keys], np.int64)
+    cols = np.array([k[1] for k in keys], np.int64)
+    x = np.array([entries[k] for k in keys], dtype=dt)
+    p = np.zeros(5, np.int64)
+    np.add.at(p, rows + 1, 1)
+    return Matrix(4, 4, Type.UDT, Sparsity.SPARSE, False, p=np.cumsum(p), i=cols, x=x)
+
+
+def _as_table(M):
+    r, c, v = M.coo()
+    out = [[None] * 4 for _ in range(4)]
+    for i, j, e in zip(r, c, v):
+        out[int(i)][int(j)] = [int(e["real"]), int(e["imag"])]
+    return out
+
+
+def test_gauss_demo_on_the_device(gba):
+    want = json.load(open(GOLDEN))
+    dt = g.register_udt(np.dtype([("real", "<i4"), ("imag", "<i4")]))
+    sr = g.user_semiring("gauss", GAUSS_DEFN, dt.itemsize, "addgauss", ADD_DEFN, "multgauss", MULT_DEFN)
+    add = ("addgauss", ADD_DEFN)
+
+    A = _gauss_matrix(dt, {(i, j): (i + 1, 2 - j) for i in range(4) for j in range(4) if (i, j) != (0, 0)})
+    dA = A.to_device()
+
+    # A = A*A
+    g.mxm_udt(dA, None, None, sr, dA, dA)
+    A2 = dA.to_host()
+    assert _as_table(A2) == want[0]["matrix"], want[0]["name"]
+
+    # C<D> = A*A', D the boolean identity
+    D = Matrix(4, 4, Type.BOOL, Sparsity.SPARSE, False, p=np.arange(5), i=np.arange(4), x=np.ones(4, bool))
+    dD = D.to_device()
+    dC = Matrix.sparse_empty(4, 4, Type.UDT).to_device()
+    g.mxm_udt(dC, dD, None, sr, dA, dA, "T1")
+    assert _as_table(dC.to_host()) == want[1]["matrix"], want[1]["name"]
+    dD.free()
+
+    # D = diag (A), then C = D*A and C = A*D
+    r, c, v = A2.coo()
+    Dg = _gauss_matrix(dt, {(int(i), int(j)): (int(e["real"]), int(e["imag"])) for i, j, e in zip(r, c, v) if i == j})
+    dDg = Dg.to_device()
+    g.mxm_udt(dC, None, None, sr, dDg, dA)
+    assert _as_table(dC.to_host()) == want[2]["matrix"], want[2]["name"]
+    g.mxm_udt(dC, None, None, sr, dA, dDg)
+    assert _as_table(dC.to_host()) == want[3]["matrix"], want[3]["name"]
+    dC.free(); dDg.free()
+
+    # C = (1,-2) everywhere (full), then C += A*A'
+    ones = np.empty((4, 4), dt)
+    ones["real"], ones["imag"] = 1, -2
+    dC = Matrix.dense(ones).to_device()
+    g.mxm_udt(dC, None, add, sr, dA, dA, "T1")
+    assert _as_table(dC.to_host()) == want[4]["matrix"], want[4]["name"]
+
+    # C += B*A and C += A*B with B = (1,-2) everywhere (full)
+    dB = Matrix.dense(ones).to_device()
+    g.mxm_udt(dC, None, add, sr, dB, dA)
+    assert _as_table(dC.to_host()) == want[5]["matrix"], want[5]["name"]
+    g.mxm_udt(dC, None, add, sr, dA, dB)
+    assert _as_table(dC.to_host()) == want[6]["matrix"], want[6]["name"]
+    for d in (dA, dB, dC):
+        d.free()
+
+
+def test_udt_compile_error_is_reported(gba):
+    dt = g.register_udt(np.dtype([("real", "<i4"), ("imag", "<i4")]))
+    bad = g.user_semiring("gauss", GAUSS_DEFN, dt.itemsize, "addgauss", ADD_DEFN, "multgauss", "void multgauss (gauss *z) { nonsense ; }")
+    A = _gauss_matrix(dt, {(0, 1): (1, 1), (1, 0): (2, 2)})
+    dA = A.to_device()
+    dC = Matrix.sparse_empty(4, 4, Type.UDT).to_device()
+    with pytest.raises(g.GrbError):
+        g.mxm_udt(dC, None, None, bad, dA, dA)
+    dA.free(); dC.free()
