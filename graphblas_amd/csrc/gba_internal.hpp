@@ -182,6 +182,9 @@ gba_info saxbit(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
                 const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep);
 gba_info transpose(gba_matrix *AT, const gba_matrix *A);
 gba_info to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owned);   // bitmap/full -> sparse copy
+// hypersparse -> sparse view over all vdim vectors (new p; i and x shared with X)
+constexpr int64_t HYPER_EXPAND_MAX = (int64_t)1 << 31;
+gba_info hyper_to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owned);
 gba_info matrix_wait(gba_matrix *C);
 
 // stage a host-resident view into device memory (PCIe); owned[] collects the

@@ -673,8 +673,20 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
     if (k.B_in->mem == GBA_MEM_HOST) { GBA_OK(stage_to_device(k.B_in, &Bdev, ex.owned)); k.B_in = &Bdev; }
     (void)M_user;
     const gba_matrix *A_in = k.A_in, *B_in = k.B_in;
-    if (is_hyper(A_in) || is_hyper(B_in) || is_hyper(C) || (k.M && is_hyper(k.M)))
-        GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse matrices stay on the CPU path");
+    // hypersparse operands are given to the kernels in sparse form (a pointer array over every vector);
+    // the result is sparse, never hypersparse
+    gba_matrix Msp, Asp, Bsp;
+    if (k.M && is_hyper(k.M)) { GBA_OK(hyper_to_sparse(k.M, &Msp, ex.owned)); k.M = &Msp; }
+    if (is_hyper(A_in)) { GBA_OK(hyper_to_sparse(A_in, &Asp, ex.owned)); k.A_in = A_in = &Asp; }
+    if (is_hyper(B_in)) { GBA_OK(hyper_to_sparse(B_in, &Bsp, ex.owned)); k.B_in = B_in = &Bsp; }
+    if (is_hyper(C)) {
+        if (select_only) GBA_FAIL(GBA_NOT_IMPLEMENTED, "method selection with a hypersparse C");
+        std::vector<void *> mine;
+        gba_matrix Csp;
+        GBA_OK(hyper_to_sparse(C, &Csp, mine));          // C owns its arrays: the new p replaces p and h
+        gba_free(C->p); gba_free(C->h);
+        *C = Csp;
+    }
     if (A_in->nzombies || B_in->nzombies || (k.M && k.M->nzombies))
         GBA_FAIL(GBA_INVALID_OBJECT, "inputs with zombies: call gba_matrix_wait first (Source/GB_mxm.c:105-116)");
 

@@ -363,6 +363,42 @@ gba_info to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owne
     return GBA_SUCCESS;
 }
 
+// ------------------------------------------------------ hypersparse -> sparse --
+// A hypersparse matrix lists its non-empty vectors in h[0..nvec) with p[nvec+1]
+// (Source/Shared/GB_matrix.h:306-360).  The kernels address vectors directly, so the front end gives
+// them the sparse form of the same matrix (GB_convert_hyper_to_sparse, Source/GB_convert_hyper_to_sparse.c):
+// a pointer array over all vdim vectors, i and x shared with the original.
+__global__ void __launch_bounds__(256)
+hyper_scatter_kernel(int64_t nvec, const int64_t *__restrict__ h, const int64_t *__restrict__ p, int64_t *__restrict__ cnt) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < nvec; k += stride) cnt[h[k]] = p[k + 1] - p[k];
+}
+
+gba_info hyper_to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owned) {
+    GBA_OK(require_init());
+    if (!is_hyper(X)) GBA_FAIL(GBA_INVALID_VALUE, "hyper_to_sparse: sparsity %d", X->sparsity);
+    if (X->vdim > HYPER_EXPAND_MAX) GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse matrix with %ld vectors (limit %ld)", (long)X->vdim, (long)HYPER_EXPAND_MAX);
+    hipStream_t st = ctx().stream;
+    const int64_t vdim = X->vdim, nvec = X->nvec;
+    DevBuf Sp;
+    GBA_OK(Sp.alloc((size_t)(vdim + 1) * 8));
+    GBA_HIP(hipMemsetAsync(Sp.p, 0, (size_t)(vdim + 1) * 8, st));
+    if (nvec > 0) {
+        if (!X->h || !X->p) GBA_FAIL(GBA_INVALID_OBJECT, "hypersparse matrix without h or p");
+        int64_t blocks = ceil_div(nvec, 256); if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(hyper_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, X->h, X->p, Sp.as<int64_t>());
+        GBA_HIP(hipGetLastError());
+    }
+    GBA_OK(dev_cumsum_i64(Sp.as<int64_t>(), vdim, st));
+    GBA_HIP(hipStreamSynchronize(st));
+    *S = *X;
+    S->p = reinterpret_cast<int64_t *>(Sp.release());
+    S->h = nullptr; S->nvec = vdim; S->sparsity = GBA_SPARSE;
+    owned.push_back(S->p);
+    return GBA_SUCCESS;
+}
+
 // --------------------------------------------------------------- transpose --
 __global__ void __launch_bounds__(256)
 transpose_count_kernel(int64_t anz, const int64_t *__restrict__ Ai, unsigned long long *__restrict__ cnt) {

@@ -24,13 +24,13 @@ class Matrix:
     """A matrix or vector on the host.  vlen/vdim/is_csc as in Source/Shared/GB_matrix.h:213-234."""
 
     def __init__(self, vlen, vdim, type, sparsity, is_csc, p=None, i=None, x=None, b=None,
-                 iso=False, jumbled=False, nzombies=0, nvals=None):
+                 iso=False, jumbled=False, nzombies=0, nvals=None, h=None):
         self.vlen, self.vdim, self.type, self.sparsity, self.is_csc = int(vlen), int(vdim), int(type), int(sparsity), bool(is_csc)
-        self.p, self.i, self.b = _as(p, np.int64), _as(i, np.int64), _as(b, np.int8)
+        self.p, self.i, self.b, self.h = _as(p, np.int64), _as(i, np.int64), _as(b, np.int8), _as(h, np.int64)
         self.x = None if x is None else np.ascontiguousarray(x, dtype=NP_TYPES[self.type])
         self.iso, self.jumbled, self.nzombies = bool(iso), bool(jumbled), int(nzombies)
         if nvals is None:
-            if sparsity == Sparsity.SPARSE:
+            if sparsity in (Sparsity.SPARSE, Sparsity.HYPERSPARSE):
                 nvals = 0 if self.i is None else len(self.i)
             elif sparsity == Sparsity.BITMAP:
                 nvals = int(np.count_nonzero(self.b))
@@ -39,6 +39,19 @@ class Matrix:
         self.nvals = int(nvals)
 
     # ---- constructors ------------------------------------------------------
+    @property
+    def nvec(self):
+        return len(self.h) if self.sparsity == Sparsity.HYPERSPARSE else self.vdim
+
+    def to_hyper(self):
+        """The same sparse matrix in hypersparse form: only the non-empty vectors are listed
+        (Source/Shared/GB_matrix.h:306-360)."""
+        assert self.sparsity == Sparsity.SPARSE
+        keep = np.nonzero(np.diff(self.p))[0]
+        p = np.concatenate([self.p[keep], self.p[-1:]]) if len(keep) else np.zeros(1, np.int64)
+        return Matrix(self.vlen, self.vdim, self.type, Sparsity.HYPERSPARSE, self.is_csc, p=p, i=self.i, x=self.x,
+                      iso=self.iso, jumbled=self.jumbled, nzombies=self.nzombies, nvals=self.nvals, h=keep)
+
     @property
     def nrows(self):
         return self.vlen if self.is_csc else self.vdim
@@ -101,9 +114,10 @@ class Matrix:
     # ---- conversions -------------------------------------------------------
     def coo(self):
         """Canonical (row, col, value) triples sorted by (row, col); zombies dropped."""
-        if self.sparsity == Sparsity.SPARSE:
+        if self.sparsity in (Sparsity.SPARSE, Sparsity.HYPERSPARSE):
             counts = np.diff(self.p)
-            vec = np.repeat(np.arange(self.vdim, dtype=np.int64), counts)
+            names = np.arange(self.vdim, dtype=np.int64) if self.sparsity == Sparsity.SPARSE else self.h
+            vec = np.repeat(names, counts)
             idx = self.i[: self.p[-1]]
             live = idx >= 0
             vec, idx = vec[live], idx[live]
@@ -126,8 +140,8 @@ class Matrix:
     def view(self, keep):
         """gba_matrix over the host arrays (mem = host); keep collects references."""
         m = gba_matrix()
-        m.vlen, m.vdim, m.nvec, m.nvals = self.vlen, self.vdim, self.vdim, self.nvals
-        for name in ("p", "i", "x", "b"):
+        m.vlen, m.vdim, m.nvec, m.nvals = self.vlen, self.vdim, self.nvec, self.nvals
+        for name in ("p", "i", "x", "b", "h"):
             a = getattr(self, name)
             if a is not None:
                 if a.size == 0:
@@ -153,10 +167,11 @@ def _host_from_view(m, reader):
         return np.frombuffer(reader(ptr, int(count) * np.dtype(dtype).itemsize), dtype=dtype).copy()
 
     dense = m.vlen * m.vdim
-    if m.sparsity == Sparsity.SPARSE:
+    if m.sparsity in (Sparsity.SPARSE, Sparsity.HYPERSPARSE):
         p = arr(m.p, m.nvec + 1, np.int64)
         nz = int(p[-1]) if len(p) else 0
-        return Matrix(m.vlen, m.vdim, t, m.sparsity, m.is_csc, p=p, i=arr(m.i, nz, np.int64),
+        h = arr(m.h, m.nvec, np.int64) if m.sparsity == Sparsity.HYPERSPARSE else None
+        return Matrix(m.vlen, m.vdim, t, m.sparsity, m.is_csc, p=p, i=arr(m.i, nz, np.int64), h=h,
                       x=arr(m.x, 1 if m.iso else nz, dt), iso=m.iso, jumbled=m.jumbled, nzombies=m.nzombies, nvals=nz)
     b = arr(m.b, dense, np.int8) if m.sparsity == Sparsity.BITMAP else None
     return Matrix(m.vlen, m.vdim, t, m.sparsity, m.is_csc, x=arr(m.x, 1 if m.iso else dense, dt), b=b,
@@ -172,8 +187,8 @@ class DeviceMatrix:
     @staticmethod
     def upload(M):
         m = gba_matrix()
-        m.vlen, m.vdim, m.nvec, m.nvals = M.vlen, M.vdim, M.vdim, M.nvals
-        for name in ("p", "i", "x", "b"):
+        m.vlen, m.vdim, m.nvec, m.nvals = M.vlen, M.vdim, M.nvec, M.nvals
+        for name in ("p", "i", "x", "b", "h"):
             a = getattr(M, name)
             if a is None:
                 continue

@@ -659,6 +659,15 @@ static bool get_entry(const gba_matrix *A, int64_t row, int64_t col, const void 
         for (int64_t p = A->p[j]; p < A->p[j + 1]; p++) if (A->i[p] == i) { *val = (const uint8_t *)A->x + (A->iso ? 0 : p) * size; return true; }
         return false;
     }
+    if (A->sparsity == GBA_HYPERSPARSE) {
+        /* vector j is present only if it is listed in h: binary search, the lookup the CPU library
+           uses when a matrix has no hyper hash (Source/Shared/GB_hyper_hash_lookup.h:16-40) */
+        int64_t lo = 0, hi = A->nvec - 1;
+        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (A->h[mid] < j) lo = mid + 1; else hi = mid; }
+        if (A->nvec == 0 || A->h[lo] != j) return false;
+        for (int64_t p = A->p[lo]; p < A->p[lo + 1]; p++) if (A->i[p] == i) { *val = (const uint8_t *)A->x + (A->iso ? 0 : p) * size; return true; }
+        return false;
+    }
     const int64_t p = j * A->vlen + i;
     if (A->sparsity == GBA_BITMAP && !A->b[p]) return false;
     *val = A->x ? (const uint8_t *)A->x + (A->iso ? 0 : p) * size : ZEROS;

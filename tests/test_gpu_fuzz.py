@@ -38,7 +38,8 @@ def _random_matrix(rng, nrows, ncols, t, fmt, by_row, density):
         return Matrix.dense(vals.astype(dt), present=pres, by_row=by_row)
     S = sp.csr_matrix(np.where(pres, vals, 0).astype(np.float64))
     S.eliminate_zeros()
-    return Matrix.from_scipy(S, type=t, by_row=by_row)
+    M = Matrix.from_scipy(S, type=t, by_row=by_row)
+    return M.to_hyper() if fmt == "hyper" else M
 
 
 def _case(seed, lo=1, hi=40):
@@ -74,6 +75,33 @@ def _case(seed, lo=1, hi=40):
 @pytest.mark.parametrize("seed", range(160))
 def test_random_call_matches_the_definition(gba, seed):
     _check(gba, seed, *_case(seed))
+
+
+def _hyper_case(seed):
+    """Like _case, with hypersparse operands, mask and C mixed in (very sparse matrices: most vectors empty)."""
+    rng = np.random.default_rng(9000 + seed)
+    sr, t, accums = SEMIRINGS[rng.integers(len(SEMIRINGS))]
+    m, k, n = (int(x) for x in rng.integers(2, 60, 3))
+    a_tran, b_tran = bool(rng.random() < 0.35), bool(rng.random() < 0.35)
+    pick = lambda: ["hyper", "hyper", "sparse", "bitmap"][rng.integers(4)]
+    A = _random_matrix(rng, *((k, m) if a_tran else (m, k)), t, pick(), bool(rng.random() < 0.5), rng.choice([0.02, 0.1]))
+    B = _random_matrix(rng, *((n, k) if b_tran else (k, n)), t, pick(), bool(rng.random() < 0.5), rng.choice([0.02, 0.1]))
+    c_fmt = ["empty", "hyper", "sparse"][rng.integers(3)]
+    c_by_row = bool(rng.random() < 0.5)
+    C0 = Matrix.sparse_empty(m, n, t, by_row=c_by_row) if c_fmt == "empty" else _random_matrix(rng, m, n, t, c_fmt, c_by_row, 0.05)
+    M = None
+    if rng.random() < 0.6:
+        M = _random_matrix(rng, m, n, Type.INT8, ["hyper", "sparse"][rng.integers(2)], bool(rng.random() < 0.5), 0.2)
+        M.x = (M.x % 2).astype(np.int8)
+    accum = accums[rng.integers(len(accums))] if rng.random() < 0.5 else None
+    desc = ("R" if rng.random() < 0.3 else "") + (("S" if rng.random() < 0.5 else "") + ("C" if rng.random() < 0.4 else "") if M is not None else "") \
+        + ("T0" if a_tran else "") + ("T1" if b_tran else "")
+    return sr, A, B, C0, M, accum, desc, False
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_call_with_hypersparse_matrices(gba, seed):
+    _check(gba, seed, *_hyper_case(seed))
 
 
 @pytest.mark.parametrize("seed", range(500, 548))

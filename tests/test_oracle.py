@@ -148,3 +148,20 @@ def test_semiring_arithmetic_corner_cases():
     assert prod("PLUS_RDIV_INT16", Type.INT16, 2, 9) == 4
     assert prod("PLUS_MIN_FP64", Type.FP64, np.nan, 2.0) == 2.0
     assert prod("LOR_GT_FP32", Type.FP32, 2.0, 1.0) == True  # noqa: E712
+
+
+def test_mxm_spec_reads_hypersparse_like_sparse():
+    """A hypersparse matrix is the same matrix: the definition gives the same C either way."""
+    A = Matrix.from_scipy(_rand_sparse(30, 40, 0.04, 21), by_row=True)
+    B = Matrix.from_scipy(_rand_sparse(40, 25, 0.04, 22), by_row=False)
+    Mk = Matrix.from_scipy(_rand_sparse(30, 25, 0.2, 23), by_row=True)
+    C0 = Matrix.from_scipy(_rand_sparse(30, 25, 0.05, 24), by_row=False)
+    Ah, Bh, Mh, Ch = A.to_hyper(), B.to_hyper(), Mk.to_hyper(), C0.to_hyper()
+    assert Ah.nvec < A.vdim and len(Ah.p) == Ah.nvec + 1
+    r0, c0, v0 = A.coo()
+    r1, c1, v1 = Ah.coo()
+    assert np.array_equal(r0, r1) and np.array_equal(c0, c1) and np.array_equal(v0, v1)
+    for desc in ("", "C", "RS"):
+        p0, x0 = oracle.mxm_spec(C0, Mk, "PLUS_FP64", "PLUS_TIMES_FP64", A, B, desc)
+        p1, x1 = oracle.mxm_spec(Ch, Mh, "PLUS_FP64", "PLUS_TIMES_FP64", Ah, Bh, desc)
+        assert np.array_equal(p0, p1) and np.array_equal(x0[p0], x1[p1])
