@@ -105,7 +105,8 @@ class gba_report(C.Structure):
                 ("flops", C.c_int64), ("kernel_ms", C.c_double), ("phase_ms", C.c_double * 8),
                 ("bin_vectors", C.c_int64 * 4), ("bin_cnz", C.c_int64 * 4), ("bin_bnz", C.c_int64 * 4),
                 ("bin_madds", C.c_int64 * 4),
-                ("panels", C.c_int64), ("panels_redone", C.c_int64), ("cnz", C.c_int64)]
+                ("panels", C.c_int64), ("panels_redone", C.c_int64), ("cnz", C.c_int64),
+                ("typecast", C.c_int32), ("reserved", C.c_int32)]
 
 
 class gba_user_semiring(C.Structure):

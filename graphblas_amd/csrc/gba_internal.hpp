@@ -73,6 +73,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // matrix predicates, named after the reference macros GB_IS_SPARSE/BITMAP/FULL
 inline bool is_sparse(const gba_matrix *A) { return A && A->sparsity == GBA_SPARSE; }
+inline bool is_real_type(int t) { return t >= GBA_BOOL && t <= GBA_FP64; }     // built-in, not complex
 inline bool is_hyper(const gba_matrix *A)  { return A && A->sparsity == GBA_HYPERSPARSE; }
 inline bool is_bitmap(const gba_matrix *A) { return A && A->sparsity == GBA_BITMAP; }
 inline bool is_full(const gba_matrix *A)   { return A && A->sparsity == GBA_FULL; }

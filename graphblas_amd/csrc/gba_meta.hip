@@ -280,6 +280,57 @@ static gba_info with_type(int code, F &&f) {
     }
 }
 
+// Typecasting of built-in types (Source/GB_casting.h:65-143, 176-215): C casts, except floating point to
+// integer (saturating, NaN -> 0) and anything to bool (x != 0, so NaN -> true).
+template <class To, class From>
+__device__ inline To cast_value(From x) {
+    if constexpr (std::is_same<To, bool>::value) return x != 0;
+    else if constexpr (std::is_floating_point<From>::value && std::is_integral<To>::value) {
+        const double d = (double)x;
+        if (isnan(d)) return 0;
+        if constexpr (std::is_signed<To>::value) {
+            if (d <= (double)std::numeric_limits<To>::min()) return std::numeric_limits<To>::min();
+        } else {
+            if (d <= 0) return 0;
+        }
+        if (d >= (double)std::numeric_limits<To>::max()) return std::numeric_limits<To>::max();
+        return (To)d;
+    } else return (To)x;
+}
+
+template <class To, class From>
+__global__ void __launch_bounds__(256)
+cast_kernel(int64_t n, const From *__restrict__ x, To *__restrict__ z) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < n; p += stride) z[p] = cast_value<To, From>(x[p]);
+}
+
+// X with its values in another built-in type: a new x array, the pattern arrays shared
+// (what GB_GETA / GB_cast_matrix do entry by entry on the CPU, Source/GB_cast_matrix.c)
+static gba_info cast_values(const gba_matrix *X, int to_type, gba_matrix *out, std::vector<void *> &owned) {
+    const int64_t n = X->iso ? 1 : (is_dense_fmt(X) ? X->vlen * X->vdim : nnz_held(X));
+    void *z = gba_malloc((size_t)(n > 0 ? n : 1) * esize_of(to_type));
+    if (!z) GBA_FAIL(GBA_OUT_OF_MEMORY, "typecast of %ld values", (long)n);
+    owned.push_back(z);
+    if (n > 0 && X->x) {
+        int64_t blocks = ceil_div(n, 256); if (blocks > 8192) blocks = 8192;
+        GBA_OK(with_type(to_type, [&](auto to) -> gba_info {
+            using To = decltype(to);
+            return with_type(X->type, [&](auto from) -> gba_info {
+                using From = decltype(from);
+                hipLaunchKernelGGL((cast_kernel<To, From>), dim3((unsigned)blocks), dim3(256), 0, ctx().stream, n,
+                                   reinterpret_cast<const From *>(X->x), reinterpret_cast<To *>(z));
+                return GBA_SUCCESS;
+            });
+        }));
+        GBA_HIP(hipGetLastError());
+    }
+    *out = *X;
+    out->x = z; out->type = to_type;
+    return GBA_SUCCESS;
+}
+
 static bool accum_op_ok(int op) {
     switch (op) {
         case GBA_FIRST: case GBA_SECOND: case GBA_ANY: case GBA_PAIR: case GBA_MIN: case GBA_MAX: case GBA_PLUS:
@@ -687,6 +738,26 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
         gba_free(C->p); gba_free(C->h);
         *C = Csp;
     }
+    // operands whose values the multiplier reads are cast to its input types (Source/GB_mxm.c:84-99 checks the
+    // compatibility; the CPU kernels cast while loading, GB_GETA)
+    gba_matrix Acast, Bcast;
+    {
+        const int mult = k.semiring.mult;
+        const bool positional = op_is_positional(mult);
+        const int first_type = (mult == GBA_PAIR) ? k.semiring.ztype : k.semiring.xtype;
+        const int second_type = (mult == GBA_PAIR) ? k.semiring.ztype : k.semiring.ytype;
+        // mult (x,y) reads x unless it is SECOND/PAIR and y unless it is FIRST/PAIR; flipxy hands B as x
+        const bool x_read = !positional && mult != GBA_SECOND && mult != GBA_PAIR;
+        const bool y_read = !positional && mult != GBA_FIRST && mult != GBA_PAIR;
+        const bool a_read = k.flipxy ? y_read : x_read, b_read = k.flipxy ? x_read : y_read;
+        const int a_want = k.flipxy ? second_type : first_type, b_want = k.flipxy ? first_type : second_type;
+        if (a_read && A_in->type != a_want && is_real_type(A_in->type) && is_real_type(a_want) && !select_only) {
+            GBA_OK(cast_values(A_in, a_want, &Acast, ex.owned)); k.A_in = A_in = &Acast; ex.rep.typecast |= 1;
+        }
+        if (b_read && B_in->type != b_want && is_real_type(B_in->type) && is_real_type(b_want) && !select_only) {
+            GBA_OK(cast_values(B_in, b_want, &Bcast, ex.owned)); k.B_in = B_in = &Bcast; ex.rep.typecast |= 2;
+        }
+    }
     if (A_in->nzombies || B_in->nzombies || (k.M && k.M->nzombies))
         GBA_FAIL(GBA_INVALID_OBJECT, "inputs with zombies: call gba_matrix_wait first (Source/GB_mxm.c:105-116)");
 
@@ -701,7 +772,9 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
                  (long)bnrows, (long)bncols, k.B_transpose ? " (transposed)" : "");
     if (k.M && (nrows(k.M) != nrows(C) || ncols(k.M) != ncols(C)))
         GBA_FAIL(GBA_DIMENSION_MISMATCH, "mask is %ld-by-%ld, output is %ld-by-%ld", (long)nrows(k.M), (long)ncols(k.M), (long)nrows(C), (long)ncols(C));
-    if (C->type != k.semiring.ztype) GBA_FAIL(GBA_NOT_IMPLEMENTED, "C has type %d, the monoid %d (typecast on write-back)", C->type, k.semiring.ztype);
+    const bool cast_T = C->type != k.semiring.ztype;          // T is cast to C's type before the write-back
+    if (cast_T && (!is_real_type(C->type) || !is_real_type(k.semiring.ztype)))
+        GBA_FAIL(GBA_DOMAIN_MISMATCH, "C has type %d, the monoid %d", C->type, k.semiring.ztype);
     if (k.has_accum && op_is_positional(k.accum.op)) GBA_FAIL(GBA_DOMAIN_MISMATCH, "positional accum");
 
     // mask shortcuts (Source/GB_mxm.c:105-114)
@@ -884,6 +957,18 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
         else gba_matrix_free_content(&T);
         T = TT;
         T.is_csc = C_is_csc;
+    }
+    if (cast_T) {
+        // Z = accum (C, cast (T)): the accumulator works in C's type (Source/GB_accum_mask.c)
+        gba_matrix Tc;
+        std::vector<void *> mine;
+        info = cast_values(&T, C->type, &Tc, mine);
+        if (info != GBA_SUCCESS) { gba_matrix_free_content(&T); return info; }
+        GBA_HIP(hipStreamSynchronize(ctx().stream));
+        gba_free(T.x);
+        T = Tc;
+        ex.rep.typecast |= 4;
+        if (report) report->typecast = ex.rep.typecast;
     }
     const bool c_empty = (nnz_held(C) == 0) && !is_full(C);
     if (!k.has_accum && (!M || ex.mask_applied) && (k.C_replace || c_empty)) {

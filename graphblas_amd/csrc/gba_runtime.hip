@@ -249,7 +249,6 @@ int boolean_rename(int op) {
     }
 }
 
-static bool is_real_type(int t) { return t >= GBA_BOOL && t <= GBA_FP64; }
 static bool is_uint_type(int t) { return t == GBA_UINT8 || t == GBA_UINT16 || t == GBA_UINT32 || t == GBA_UINT64; }
 
 // GB_AxB_semiring_builtin (Source/GB_AxB_semiring_builtin.c:20-123) +

@@ -177,6 +177,8 @@ typedef struct gba_report {
     int64_t panels;         /* saxpy3 numeric, heavy vectors: LDS panels swept, and panels redone at   */
     int64_t panels_redone;  /* half width after a table overflow                                      */
     int64_t cnz;            /* entries produced (saxpy3, dot3) */
+    int32_t typecast;       /* bit 0: A's values were cast to the multiplier's type, bit 1: B's, bit 2: T to C's type */
+    int32_t reserved;
 } gba_report;
 
 /* ------------------------------------------------------ library + memory -- */

@@ -674,24 +674,73 @@ static bool get_entry(const gba_matrix *A, int64_t row, int64_t col, const void 
     return true;
 }
 
+/* Typecasting of built-in types (Source/GB_casting.h:65-143, 176-215): C casts, except that a
+ * floating-point value becomes an integer by saturation with NaN -> 0, and anything becomes bool by
+ * comparison with zero (so NaN -> true). */
+void orc_cast(void *z, int ztype, const void *x, int xtype) {
+    double d = 0; int64_t si = 0; uint64_t ui = 0; int kind;           /* 0 signed, 1 unsigned, 2 floating */
+    switch (xtype) {
+        case GBA_BOOL:   ui = *(const uint8_t *)x != 0; kind = 1; break;
+        case GBA_INT8:   si = *(const int8_t *)x;   kind = 0; break;
+        case GBA_INT16:  si = *(const int16_t *)x;  kind = 0; break;
+        case GBA_INT32:  si = *(const int32_t *)x;  kind = 0; break;
+        case GBA_INT64:  si = *(const int64_t *)x;  kind = 0; break;
+        case GBA_UINT8:  ui = *(const uint8_t *)x;  kind = 1; break;
+        case GBA_UINT16: ui = *(const uint16_t *)x; kind = 1; break;
+        case GBA_UINT32: ui = *(const uint32_t *)x; kind = 1; break;
+        case GBA_UINT64: ui = *(const uint64_t *)x; kind = 1; break;
+        case GBA_FP32:   d = (double)*(const float *)x; kind = 2; break;
+        default:         d = *(const double *)x;    kind = 2; break;
+    }
+#define ORC_TO_SIGNED(T, LO, HI) \
+    *(T *)z = kind == 2 ? (isnan(d) ? 0 : d <= (double)(LO) ? (LO) : d >= (double)(HI) ? (HI) : (T)d) : kind == 0 ? (T)si : (T)ui; break
+#define ORC_TO_UNSIGNED(T, HI) \
+    *(T *)z = kind == 2 ? ((isnan(d) || d <= 0) ? 0 : d >= (double)(HI) ? (HI) : (T)d) : kind == 0 ? (T)si : (T)ui; break
+    switch (ztype) {
+        case GBA_BOOL:   *(uint8_t *)z = kind == 2 ? (d != 0) : kind == 0 ? (si != 0) : (ui != 0); break;
+        case GBA_INT8:   ORC_TO_SIGNED(int8_t, INT8_MIN, INT8_MAX);
+        case GBA_INT16:  ORC_TO_SIGNED(int16_t, INT16_MIN, INT16_MAX);
+        case GBA_INT32:  ORC_TO_SIGNED(int32_t, INT32_MIN, INT32_MAX);
+        case GBA_INT64:  ORC_TO_SIGNED(int64_t, INT64_MIN, INT64_MAX);
+        case GBA_UINT8:  ORC_TO_UNSIGNED(uint8_t, UINT8_MAX);
+        case GBA_UINT16: ORC_TO_UNSIGNED(uint16_t, UINT16_MAX);
+        case GBA_UINT32: ORC_TO_UNSIGNED(uint32_t, UINT32_MAX);
+        case GBA_UINT64: ORC_TO_UNSIGNED(uint64_t, UINT64_MAX);
+        case GBA_FP32:   *(float *)z = kind == 2 ? (xtype == GBA_FP32 ? *(const float *)x : (float)d) : kind == 0 ? (float)si : (float)ui; break;
+        default:         *(double *)z = kind == 2 ? d : kind == 0 ? (double)si : (double)ui; break;
+    }
+#undef ORC_TO_SIGNED
+#undef ORC_TO_UNSIGNED
+}
+
 int orc_mxm_spec(int8_t *present, void *value, int64_t nrows, int64_t ncols, int64_t inner,
                  const gba_matrix *C, const gba_matrix *M, const gba_binop *accum, const gba_semiring *sr_in,
                  const gba_matrix *A, bool A_tran, const gba_matrix *B, bool B_tran, bool flipxy,
                  bool C_replace, bool Mask_comp, bool Mask_struct) {
     orc_semiring s;
     if (orc_semiring_builtin(&s, sr_in, false) != 0) return -1;
-    const size_t zs = s.zsize;
+    /* value[] and the accumulator have the type of C; T is cast to it before the accumulator sees it, and
+       the operands are cast to the multiplier's input types (Source/GB_mxm.c:84-99; GB_accum_mask) */
+    const size_t zs = orc_type_size(C->type);
+    const bool cast_t = (C->type != s.ztype);
+    const bool cast_a = !s.positional && A->type != s.xtype, cast_b = !s.positional && B->type != s.xtype;
+    if (cast_t && s.ztype == GBA_UDT) return -1;
     binfn facc = NULL;
-    if (accum && accum->op != GBA_NOP) { facc = lookup_binop(accum->type == GBA_BOOL ? bool_rename(accum->op) : accum->op, accum->type); if (!facc) return -1; }
+    if (accum && accum->op != GBA_NOP) {
+        if (accum->type != C->type) return -1;
+        facc = lookup_binop(accum->type == GBA_BOOL ? bool_rename(accum->op) : accum->op, accum->type); if (!facc) return -1;
+    }
     #pragma omp parallel for schedule(dynamic, 4)
     for (int64_t r = 0; r < nrows; r++)
         for (int64_t c = 0; c < ncols; c++) {
             /* T(r,c) = sum_k A(r,k)*B(k,c), terms in increasing k */
-            uint8_t t[32], tk[32]; bool t_in = false;
+            uint8_t t[32], tk[32], ca[32], cb[32]; bool t_in = false;
             for (int64_t k = 0; k < inner; k++) {
                 const void *a, *b;
                 if (!get_entry(A, A_tran ? k : r, A_tran ? r : k, &a, orc_type_size(A->type))) continue;
                 if (!get_entry(B, B_tran ? c : k, B_tran ? k : c, &b, orc_type_size(B->type))) continue;
+                if (cast_a) { orc_cast(ca, s.xtype, a, A->type); a = ca; }
+                if (cast_b) { orc_cast(cb, s.xtype, b, B->type); b = cb; }
                 if (s.positional) {
                     /* positional ops refer to the user's operands: i = row of A entry, etc. */
                     int64_t v; int op = sr_in->mult;
@@ -703,11 +752,12 @@ int orc_mxm_spec(int8_t *present, void *value, int64_t nrows, int64_t ncols, int
                         case GBA_SECONDJ: v = c; break;  case GBA_SECONDJ1: v = c + 1; break;
                         default: v = 0;
                     }
-                    if (zs == 4) *(int32_t *)tk = (int32_t)v; else *(int64_t *)tk = v;
+                    if (s.zsize == 4) *(int32_t *)tk = (int32_t)v; else *(int64_t *)tk = v;
                 } else if (flipxy) s.fmult(tk, b, a);
                 else s.fmult(tk, a, b);
-                if (t_in) s.fadd(t, t, tk); else { memcpy(t, tk, zs); t_in = true; }
+                if (t_in) s.fadd(t, t, tk); else { memcpy(t, tk, s.zsize); t_in = true; }
             }
+            if (t_in && cast_t) { uint8_t tc[32]; orc_cast(tc, C->type, t, s.ztype); memcpy(t, tc, zs); }
             /* Z = accum (C,T); C<M,replace> = Z */
             const void *cv; const bool c_in = get_entry(C, r, c, &cv, zs);
             bool m = true;

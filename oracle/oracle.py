@@ -48,6 +48,8 @@ def dll():
         d.orc_saxbit.argtypes = [M, M, C.c_bool, C.c_bool, M, M, S]
         d.orc_mxm_spec.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, M, M, P(gba_binop),
                                    P(gba_semiring), M, C.c_bool, M, C.c_bool, C.c_bool, C.c_bool, C.c_bool, C.c_bool]
+        d.orc_cast.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        d.orc_cast.restype = None
         d.orc_matrix_wait.argtypes = [M]
         d.orc_matrix_free_content.argtypes = [M]
         d.orc_gauss_replay.argtypes = [C.c_char_p, C.c_size_t]
@@ -155,12 +157,22 @@ def mxm_spec(Cm, Mask, accum, semiring, A, B, desc="", flipxy=False, A_tran=None
     nrows, ncols = Cm.nrows, Cm.ncols
     inner = A.nrows if A_tran else A.ncols
     present = np.zeros(nrows * ncols, np.int8)
-    value = np.zeros(nrows * ncols, NP_TYPES[s.ztype])
+    value = np.zeros(nrows * ncols, NP_TYPES[Cm.type])
     keep = []
     _chk(dll().orc_mxm_spec(present.ctypes.data, value.ctypes.data, nrows, ncols, inner, _v(Cm, keep), _v(Mask, keep),
                             C.byref(a) if a is not None else None, C.byref(s), _v(A, keep), A_tran, _v(B, keep), B_tran,
                             flipxy, "R" in d, "C" in d, "S" in d), "mxm_spec")
     return present.reshape(nrows, ncols).astype(bool), value.reshape(nrows, ncols)
+
+
+def cast(values, from_type, to_type):
+    """Typecast an array of a built-in type entry by entry (Source/GB_casting.h)."""
+    src = np.ascontiguousarray(values, NP_TYPES[from_type])
+    out = np.zeros(src.shape, NP_TYPES[to_type])
+    f, t, d = src.dtype.itemsize, out.dtype.itemsize, dll()
+    for q in range(src.size):
+        d.orc_cast(out.ctypes.data + q * t, int(to_type), src.ctypes.data + q * f, int(from_type))
+    return out
 
 
 def gauss_replay():

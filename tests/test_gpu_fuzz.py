@@ -104,6 +104,61 @@ def test_random_call_with_hypersparse_matrices(gba, seed):
     _check(gba, seed, *_hyper_case(seed))
 
 
+CAST_TYPES = [Type.BOOL, Type.INT8, Type.UINT8, Type.INT16, Type.UINT16, Type.INT32, Type.UINT32, Type.INT64, Type.UINT64,
+              Type.FP32, Type.FP64]
+
+
+def _typed_matrix(rng, nrows, ncols, t, fmt, by_row, density):
+    """Entries that do not survive a typecast unchanged: halves, negatives, values past 8 and 16 bits."""
+    dt = np.dtype(NP_TYPES[t])
+    pool = np.array([-300.5, -2.5, -1, 0.5, 1, 2, 3.5, 70000, 129, 255.5])
+    vals = pool[rng.integers(len(pool), size=(nrows, ncols))]
+    if dt.kind in "iu":                       # wrapped into the type's range; magnitudes stay small enough that
+        v = np.trunc(np.abs(vals) if dt.kind == "u" else vals).astype(np.int64)      # fp32 sums are exact in any order
+        vals = v.astype(dt)                   # int64 -> narrower integer wraps
+    else:
+        vals = vals.astype(dt) if dt.kind != "b" else (vals > 1)
+    pres = rng.random((nrows, ncols)) < density
+    if fmt == "full":
+        return Matrix.dense(vals, by_row=by_row, type=t)
+    if fmt == "bitmap":
+        return Matrix.dense(vals, present=pres, by_row=by_row, type=t)
+    r, c = np.nonzero(pres)
+    if not by_row:
+        o = np.lexsort((r, c)); r, c = r[o], c[o]
+    vec, idx, nv = (r, c, nrows) if by_row else (c, r, ncols)
+    p = np.zeros(nv + 1, np.int64)
+    np.add.at(p, vec + 1, 1)
+    return Matrix(ncols if by_row else nrows, nv, t, 2, not by_row, p=np.cumsum(p), i=idx, x=vals[r, c])
+
+
+def _cast_case(seed):
+    rng = np.random.default_rng(7000 + seed)
+    sr, t, _ = SEMIRINGS[rng.integers(len(SEMIRINGS))]
+    m, k, n = (int(x) for x in rng.integers(1, 30, 3))
+    ta, tb, tc = (CAST_TYPES[rng.integers(len(CAST_TYPES))] for _ in range(3))
+    fm = lambda: ["sparse", "sparse", "bitmap", "full"][rng.integers(4)]
+    A = _typed_matrix(rng, m, k, ta, fm(), bool(rng.random() < 0.5), 0.4)
+    B = _typed_matrix(rng, k, n, tb, fm(), bool(rng.random() < 0.5), 0.4)
+    c_by_row = bool(rng.random() < 0.5)
+    C0 = Matrix.sparse_empty(m, n, tc, by_row=c_by_row) if rng.random() < 0.3 else _typed_matrix(rng, m, n, tc, fm(), c_by_row, 0.3)
+    M = None
+    if rng.random() < 0.5:
+        M = _random_matrix(rng, m, n, Type.INT8, ["sparse", "bitmap", "full"][rng.integers(3)], bool(rng.random() < 0.5), 0.4)
+        M.x = (M.x % 2).astype(np.int8)
+    tname = {v: k_ for k_, v in vars(Type).items() if isinstance(v, int)}[tc]
+    ops = ["LOR", "LXOR"] if tc == Type.BOOL else ["PLUS", "MIN", "MAX", "SECOND", "FIRST"]
+    accum = f"{ops[rng.integers(len(ops))]}_{tname}" if rng.random() < 0.5 else None
+    desc = ("R" if rng.random() < 0.3 else "") + (("S" if rng.random() < 0.5 else "") + ("C" if rng.random() < 0.4 else "") if M is not None else "")
+    return sr, A, B, C0, M, accum, desc, False
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_call_with_typecasts(gba, seed):
+    """Operands and C of types other than the semiring's: cast while loading and on the write-back."""
+    _check(gba, seed, *_cast_case(seed))
+
+
 @pytest.mark.parametrize("seed", range(500, 548))
 def test_random_call_matches_the_definition_larger(gba, seed):
     """Dimensions of 120..320: vectors reach the block-level hash kernels and the long-row dot paths."""

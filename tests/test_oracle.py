@@ -165,3 +165,29 @@ def test_mxm_spec_reads_hypersparse_like_sparse():
         p0, x0 = oracle.mxm_spec(C0, Mk, "PLUS_FP64", "PLUS_TIMES_FP64", A, B, desc)
         p1, x1 = oracle.mxm_spec(Ch, Mh, "PLUS_FP64", "PLUS_TIMES_FP64", Ah, Bh, desc)
         assert np.array_equal(p0, p1) and np.array_equal(x0[p0], x1[p1])
+
+
+def test_typecast_rules():
+    """Source/GB_casting.h: floating point to integer saturates and sends NaN to 0; anything to bool is x != 0."""
+    x = np.array([np.nan, -np.inf, np.inf, -1.5, 2.9, 300.0, -200.0, 3e9, -3e9, 1e20, 0.0], np.float64)
+    assert oracle.cast(x, Type.FP64, Type.INT8).tolist() == [0, -128, 127, -1, 2, 127, -128, 127, -128, 127, 0]
+    assert oracle.cast(x, Type.FP64, Type.UINT8).tolist() == [0, 0, 255, 0, 2, 255, 0, 255, 0, 255, 0]
+    assert oracle.cast(x, Type.FP64, Type.INT32).tolist() == [0, -2**31, 2**31 - 1, -1, 2, 300, -200, 2**31 - 1, -2**31, 2**31 - 1, 0]
+    assert oracle.cast(x, Type.FP64, Type.UINT64).tolist() == [0, 0, 2**64 - 1, 0, 2, 300, 0, 3000000000, 0, 2**64 - 1, 0]
+    assert oracle.cast(x, Type.FP64, Type.BOOL).tolist() == [True, True, True, True, True, True, True, True, True, True, False]
+    i = np.array([-1, 300, -129, 65536 + 7], np.int32)
+    assert oracle.cast(i, Type.INT32, Type.UINT8).tolist() == [255, 44, 127, 7]          # integer to integer: C's modular cast
+    assert oracle.cast(i, Type.INT32, Type.INT8).tolist() == [-1, 44, 127, 7]
+    assert oracle.cast(i, Type.INT32, Type.FP32).tolist() == [-1.0, 300.0, -129.0, 65543.0]
+    assert oracle.cast(np.array([2.5], np.float32), Type.FP32, Type.INT64).tolist() == [2]
+
+
+def test_mxm_spec_typecasts_operands_and_result():
+    """A int8 and B fp64 under PLUS_TIMES_INT32 into an fp32 C with a PLUS_FP32 accumulator."""
+    A = Matrix.dense(np.array([[1, 2], [3, 4]], np.int8))
+    B = Matrix.dense(np.array([[0.5, 1.9], [2.2, -1.7]], np.float64))
+    C0 = Matrix.dense(np.array([[10, 20], [30, 40]], np.float32))
+    p, v = oracle.mxm_spec(C0, None, "PLUS_FP32", "PLUS_TIMES_INT32", A, B)
+    Bi = np.array([[0, 1], [2, -1]])                # B cast to int32 truncates toward zero
+    want = np.array([[10, 20], [30, 40]]) + np.array([[1, 2], [3, 4]]) @ Bi
+    assert p.all() and v.dtype == np.float32 and np.array_equal(v, want.astype(np.float32))
