@@ -188,7 +188,7 @@ def main():
             "panels_rank0": [int(stats.get("panels", 0)) // max(args.steps, 1), int(stats.get("panels_redone", 0)) // max(args.steps, 1)],
             "generate_s": round(gen_s, 1),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on the one-GPU run only
             out["cpu_baseline"] = cpu_baseline(A, rf, args.cpu_flops)
         print(json.dumps(out), flush=True)
     if world > 1:
