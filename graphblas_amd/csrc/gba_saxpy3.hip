@@ -955,7 +955,7 @@ __device__ inline int64_t first_ge(const int32_t *__restrict__ X, int64_t lo, in
 // append and the call; ends on a barrier with the queue empty.
 template <int PANEL_UNROLL, class Load, class Apply>
 __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSegs *S, Load load, Apply apply) {
-    static_assert(PANEL_SEGCAP == 4 * PANEL_THREADS, "four queue entries per thread in the scan");
+    static_assert(PANEL_SEGCAP == 4 * PANEL_THREADS && PANEL_SEGCAP <= 64 * 64, "four queue entries per thread in the scan; two 64-way steps find a run");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     GBA_TICK(tke0);
     const int b4 = tid * 4;
@@ -994,9 +994,7 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
         const uint32_t per = (nwin + NWAVES - 1) / NWAVES;
         uint32_t win = (uint32_t)wv * per;
         const uint32_t win_end = (win + per < nwin) ? win + per : nwin;
-        int top = 1;                                    // largest power of two below n (bisection stride)
-        while (top * 2 < n) top <<= 1;
-        int sb = 0;                                     // windows come in increasing order: never search below the last run
+        int sb = 0;
         bool placed = false;
         unsigned long long *wm = S->wmask[wv];
         while (true) {
@@ -1009,10 +1007,15 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
             }
             const uint64_t w0 = (uint64_t)win * WIN;
             if (dynamic || !placed) {
-                for (int step = top; step > 0; step >>= 1) {    // largest s >= sb with off[s] <= w0
-                    const int idx = sb + step;
-                    if (idx < n && (uint64_t)S->off[idx] <= w0) sb = idx;
-                }
+                // largest s with off[s] <= w0 (off[0] = 0), in two 64-way steps: every stride-th prefix sum,
+                // then the stride of them that brackets w0 (n <= 64 * 64)
+                const int stride = (n + 63) >> 6;
+                const int i1 = lane * stride;
+                const unsigned long long m1 = __ballot(i1 < n && (uint64_t)S->off[i1 < n ? i1 : 0] <= w0);
+                const int blk = (int)__builtin_popcountll(m1) - 1;
+                const int i2 = blk * stride + lane;
+                const unsigned long long m2 = __ballot(lane < stride && i2 < n && (uint64_t)S->off[i2 < n ? i2 : 0] <= w0);
+                sb = blk * stride + (int)__builtin_popcountll(m2) - 1;
                 placed = true;
             }
             const uint64_t wend = w0 + WIN;
@@ -1071,6 +1074,107 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
     GBA_TOCK(S, 3, tke1, tke2); GBA_TOCK(S, 4, tke2, tke3);
 }
 
+// First p in [u,e) with X[p] >= target (e if none), found by the G lanes of a group together: the lanes
+// probe G positions a stride apart, the stride grows G-fold while every probe is below the target and
+// shrinks G-fold once one is not, so a run of r entries costs about 2 log_G r dependent loads instead of
+// 2 log_2 r.  G is a power of two <= 64 and a group sits inside one wave; gl = lane within the group,
+// gb = first lane of the group.  Every lane of the wave must call (the loop is wave-uniform); groups
+// with act == false only keep the others company.  Returns the index found at p through nv
+// (PANEL_INF when p == e).
+__device__ inline void group_first_ge(const int32_t *__restrict__ X, bool act, int64_t u, int64_t e, int64_t target,
+                                      int lgG, int gl, int gb, int64_t &p, int64_t &nv) {
+    const int G = 1 << lgG;
+    const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    int64_t hi = e, s = 1;
+    int32_t hv = 0;
+    if (u > hi) u = hi;
+    bool run = act && u < hi;
+    while (__ballot(run)) {
+        const int64_t pos = u + (int64_t)(gl + 1) * s - 1;
+        const bool inb = run && pos < hi;
+        const int32_t xv = inb ? X[pos] : 0;
+        const unsigned long long bal = __ballot(inb && (int64_t)xv < target);
+        const int cnt = (int)__builtin_popcountll((bal >> gb) & gmask);     // probes below the target: a prefix of the group
+        const int src = gb + ((cnt < G) ? cnt : G - 1);
+        const int32_t fv = __shfl(xv, src, 64);                             // the first probe that was not
+        const int fin = __shfl((int)inb, src, 64);
+        if (run) {
+            if (cnt == G) { u += s << lgG; s <<= lgG; }
+            else {
+                u += (int64_t)cnt * s;
+                if (fin) { hi = u + s - 1; hv = fv; }
+                s = (s + G - 1) >> lgG;
+            }
+            if (u >= hi) { u = hi; run = false; }
+        }
+    }
+    p = u;
+    nv = (u < e) ? (int64_t)hv : PANEL_INF;
+}
+
+// panel_walk for a vector with few neighbours (deg * 2 <= PANEL_THREADS): their runs inside a panel are
+// long, so each neighbour gets a group of lanes that searches its list together (group_first_ge).
+template <int PANEL_UNROLL, class Load, class Apply>
+__device__ inline void panel_walk_groups(const SpView &A, const SpView &B, int64_t pB0, int64_t deg, int64_t ibeg,
+                                         int64_t pend, int64_t iend, bool first, const PanelCursors &pc, PanelSegs *S,
+                                         Load load, Apply apply) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int32_t *__restrict__ Ai = A.i32;
+    int lgG = 6;
+    while (lgG > 0 && ((int64_t)deg << lgG) > PANEL_THREADS) lgG--;
+    const int G = 1 << lgG, gl = tid & (G - 1), gb = lane & ~(G - 1);
+    const int64_t t = tid >> lgG;
+    const bool live = t < deg;
+    GBA_TICK(tk0);
+    int64_t c = 0, e = 0, nv = PANEL_INF;
+    if (live) {
+        if (first) {
+            const int64_t k = B.i[pB0 + t];
+            c = A.p[k]; e = A.p[k + 1];
+            if (gl == 0) pc.end[t] = e;
+        } else {
+            c = pc.cur_in[t]; nv = pc.nv_in[t]; e = pc.end[t];
+        }
+    }
+    if (first) {
+        if (ibeg > 0) group_first_ge(Ai, live, c, e, ibeg, lgG, gl, gb, c, nv);
+        else if (live && c < e) nv = Ai[c];
+    }
+    const bool need = live && nv < pend;
+    int64_t stop = c, nv2 = nv;
+    if (pend >= PANEL_INF) { if (need) { stop = e; nv2 = PANEL_INF; } }
+    else {
+        int64_t ps = c, pn = nv;
+        group_first_ge(Ai, need, c + 1, e, pend, lgG, gl, gb, ps, pn);      // Ai[c] = nv < pend where need
+        if (need) { stop = ps; nv2 = pn; }
+    }
+    const bool writer = live && gl == 0;
+    if (writer) {
+        pc.cur_out[t] = stop;
+        pc.nv_out[t] = nv2;
+        if (nv2 < iend) S->more = 1;
+    }
+    const bool has = writer && stop > c;
+    const unsigned long long m = __ballot(has);
+    if (m) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&S->nseg, (int)__builtin_popcountll(m));
+        slot = __shfl(slot, 0, 64);
+        if (has) {
+            slot += (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            S->where[slot] = ((unsigned long long)c << PANEL_T_BITS) | (unsigned long long)t;
+            S->off[slot] = (uint32_t)(stop - c);
+        }
+    }
+    GBA_TICK(tk1);
+    __syncthreads();
+    GBA_TICK(tk2);
+    GBA_TOCK(S, 0, tk0, tk1); GBA_TOCK(S, 1, tk1, tk2);
+    const int ns = S->nseg;
+    if (ns > 0) panel_expand<PANEL_UNROLL>(A, pB0, ns, S, load, apply);
+    else __syncthreads();
+}
+
 // Visit the products A(i,k)*B(k,j) with ibeg <= i < pend that have not been
 // visited yet (iend = end of the whole sweep; pend = PANEL_INF takes all that
 // is left).  PANEL_STEP neighbours at a time: each thread advances the cursors
@@ -1083,6 +1187,10 @@ template <int PANEL_UNROLL, class Load, class Apply>
 __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0, int64_t deg, int64_t ibeg,
                                   int64_t pend, int64_t iend, bool first, const PanelCursors &pc, PanelSegs *S,
                                   Load load, Apply apply) {
+    if (deg * 2 <= PANEL_THREADS) {
+        panel_walk_groups<PANEL_UNROLL>(A, B, pB0, deg, ibeg, pend, iend, first, pc, S, load, apply);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int32_t *__restrict__ Ai = A.i32;
     for (int64_t t0 = 0; t0 < deg; t0 += PANEL_STEP) {
@@ -1099,7 +1207,8 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
                     c[q] = A.p[k]; e[q] = A.p[k + 1];
                     pc.end[t] = e[q];
                 } else {
-                    c[q] = pc.cur_in[t]; nv[q] = pc.nv_in[t];
+                    // the end of the list is fetched with the cursor, not after the test that needs it
+                    c[q] = pc.cur_in[t]; nv[q] = pc.nv_in[t]; e[q] = pc.end[t];
                 }
             }
         }
@@ -1114,9 +1223,11 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
 #pragma unroll
         for (int q = 0; q < PANEL_NPT; q++) {
             need[q] = live[q] && nv[q] < pend;
-            if (need[q] && !first) e[q] = pc.end[t0 + (int64_t)q * PANEL_THREADS + tid];
             stop[q] = c[q];
         }
+        int64_t hp[PANEL_NPT]; int32_t hv[PANEL_NPT];       // last probe that met an index >= pend: where, and the index
+#pragma unroll
+        for (int q = 0; q < PANEL_NPT; q++) { hp[q] = -1; hv[q] = 0; }
         if (pend >= PANEL_INF) {
 #pragma unroll
             for (int q = 0; q < PANEL_NPT; q++) if (need[q]) stop[q] = e[q];
@@ -1138,7 +1249,8 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
                 any = false;
 #pragma unroll
                 for (int q = 0; q < PANEL_NPT; q++) {
-                    if (inb[q] && xv[q] < pend) { lo[q] = pos[q]; st[q] <<= 1; } else g[q] = false;
+                    if (inb[q] && xv[q] < pend) { lo[q] = pos[q]; st[q] <<= 1; }
+                    else { if (inb[q]) { hp[q] = pos[q]; hv[q] = xv[q]; } g[q] = false; }
                     any |= g[q];
                 }
             }
@@ -1162,7 +1274,7 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
                 any = false;
 #pragma unroll
                 for (int q = 0; q < PANEL_NPT; q++) {
-                    if (act[q]) { if (xv[q] < pend) a[q] = m[q] + 1; else b[q] = m[q]; }
+                    if (act[q]) { if (xv[q] < pend) a[q] = m[q] + 1; else { b[q] = m[q]; hp[q] = m[q]; hv[q] = xv[q]; } }
                     any |= a[q] < b[q];
                 }
             }
@@ -1174,7 +1286,7 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
             const int64_t t = t0 + (int64_t)q * PANEL_THREADS + tid;
             if (live[q]) {
                 int64_t nv2 = nv[q];
-                if (need[q]) nv2 = (stop[q] < e[q]) ? Ai[stop[q]] : PANEL_INF;
+                if (need[q]) nv2 = (stop[q] < e[q]) ? ((stop[q] == hp[q]) ? (int64_t)hv[q] : (int64_t)Ai[stop[q]]) : PANEL_INF;
                 pc.cur_out[t] = stop[q];
                 pc.nv_out[t] = nv2;
                 if (nv2 < iend) S->more = 1;

@@ -109,6 +109,66 @@ def test_hub_vectors_are_cut_into_several_tasks(gba, sr):
     assert_same(got, want, exact=True, what=sr)
 
 
+def _few_long_neighbours(n, degs, hub_len, seed, nhubs=520):
+    """B(:,j) names degs[j] columns of A, all of them long: heavy vectors with few neighbours, whose
+    runs inside one panel are long (the searches are shared by groups of lanes)."""
+    rng = np.random.default_rng(seed)
+    hubs = rng.choice(n, nhubs, replace=False)
+    rows, cols = [], []
+    for h in hubs:
+        ln = int(hub_len * rng.uniform(0.3, 1.0))
+        rows.append(rng.choice(n, ln, replace=False)); cols.append(np.full(ln, h))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    A = sp.coo_matrix((rng.integers(1, 4, len(rows)).astype(np.float64), (rows, cols)), shape=(n, n)).tocsc()
+    br = [np.sort(rng.choice(hubs, d, replace=False)) for d in degs]
+    bc = [np.full(len(k), j) for j, k in enumerate(br)]
+    br, bc = np.concatenate(br), np.concatenate(bc)
+    B = sp.coo_matrix((rng.integers(1, 4, len(br)).astype(np.float64), (br, bc)), shape=(n, len(degs))).tocsc()
+    return A, B
+
+
+@pytest.mark.parametrize("sr", ["PLUS_TIMES_FP64", "MIN_FIRSTJ_INT64"])
+def test_heavy_vectors_with_few_neighbours(gba, sr):
+    """1 to 512 neighbours per vector: every group size of the shared search, and the per-thread search above."""
+    t = Type.FP64 if sr.endswith("FP64") else Type.INT64
+    degs = [1, 2, 3, 5, 8, 9, 16, 17, 31, 33, 64, 100, 128, 200, 256, 400, 512, 513, 520]
+    As, Bs = _few_long_neighbours(150_000, degs, 40_000, seed=5)
+    A, B = _mat(As, t), _mat(Bs, t)
+    got, rep = _run(gba, A, B, sr)
+    want = oracle.saxpy3(None, False, False, A, B, sr)
+    assert rep.bin_vectors[3] == len(degs)
+    assert_same(got, want, exact=True, what=sr)
+
+
+def test_few_neighbours_split_into_tasks(gba):
+    """A vector of more than 4e6 multiply-adds is split, and a later task starts its sweep in the middle of the
+    lists: the first search is for the task's first index."""
+    degs = [6, 12, 40]
+    As, Bs = _few_long_neighbours(1_200_000, degs, 1_000_000, seed=6, nhubs=40)
+    A, B = _mat(As), _mat(Bs)
+    dA, dB = A.to_device(), B.to_device()
+    mw, fl = gba.AxB_saxpy3_flopcount(None, False, dA, dB)
+    dA.free(); dB.free()
+    assert np.diff(fl).max() > 2 * 4_000_000 and np.diff(fl)[1] > 4_000_000
+    got, rep = _run(gba, A, B, "PLUS_TIMES_FP64")
+    want = oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64")
+    assert_same(got, want, exact=True)
+
+
+def test_few_neighbours_masked(gba):
+    degs = [6, 40, 250]
+    As, Bs = _few_long_neighbours(100_000, degs, 30_000, seed=7)
+    A, B = _mat(As), _mat(Bs)
+    rng = np.random.default_rng(8)
+    Ms = sp.random(100_000, len(degs), density=0.3, random_state=rng, format="csc")
+    Ms.data[:] = 1
+    M = _mat(Ms, Type.BOOL)
+    for comp in (False, True):
+        got, rep = _run(gba, A, B, "PLUS_TIMES_FP64", M, comp, True)
+        want = oracle.saxpy3(M, comp, True, A, B, "PLUS_TIMES_FP64")
+        assert_same(got, want, exact=True, what=f"comp={comp}")
+
+
 @pytest.mark.parametrize("sr,t", [
     ("PLUS_TIMES_INT8", Type.INT8), ("PLUS_TIMES_UINT16", Type.UINT16), ("PLUS_TIMES_FP32", Type.FP32),
     ("MIN_PLUS_FP64", Type.FP64), ("MAX_MIN_INT32", Type.INT32), ("LOR_LAND_BOOL", Type.BOOL),
