@@ -567,6 +567,21 @@ __device__ inline typename S::z_t product(const S &sr, const SpView &A, const Sp
     return sr.mult(a, b, i, k, j);
 }
 
+// what one product reads, fetched apart from the multiply so that the loads can be issued early
+template <class S>
+struct PanelOperands { typename S::x_t a, b; int64_t k; };
+
+template <class S>
+__device__ inline PanelOperands<S> fetch_operands(const S &sr, const SpView &A, const SpView &B, bool apat, bool bpat,
+                                                  int64_t pA, int64_t pB) {
+    using X = typename S::x_t;
+    PanelOperands<S> r;
+    r.a = load_x<X>(reinterpret_cast<const X *>(A.x), pA, A.iso, apat);
+    r.b = load_x<X>(reinterpret_cast<const X *>(B.x), pB, B.iso, bpat);
+    r.k = S::positional ? B.i[pB] : 0;
+    return r;
+}
+
 template <class S>
 __global__ void __launch_bounds__(256)
 num_wave_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int lpa,
@@ -997,13 +1012,20 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
         int sb = 0;
         bool placed = false;
         unsigned long long *wm = S->wmask[wv];
-        while (true) {
+        using Raw = decltype(load(0, (int64_t)0, (int64_t)0));
+        // One window: take it, find the run of each of its products, and ISSUE the loads of what the products
+        // need (index of A, and whatever load() fetches).  Nothing loaded is touched here, so the caller can
+        // work on the window before while these loads are in flight.  When no window is left (returns
+        // false) the first window is staged again with every product switched off: the same loads are
+        // issued on every path, which lets the compiler count them instead of draining the queue.
+        auto stage = [&](int32_t (&ii)[PANEL_UNROLL], Raw (&raw)[PANEL_UNROLL], bool (&ok)[PANEL_UNROLL]) -> bool {
+            bool real = true;
             if (dynamic) {
                 if (lane == 0) win = atomicAdd(&S->wnext, 1u);
                 win = __shfl(win, 0, 64);
-                if (win >= nwin) break;
+                if (win >= nwin) { real = false; win = 0; }
             } else if (win >= win_end) {
-                break;
+                real = false; win = 0; placed = false; sb = 0;
             }
             const uint64_t w0 = (uint64_t)win * WIN;
             if (dynamic || !placed) {
@@ -1034,14 +1056,18 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
             unsigned long long mk[PANEL_UNROLL];
             int starts = 0;
 #pragma unroll
-            for (int u = 0; u < PANEL_UNROLL; u++) { mk[u] = ((volatile unsigned long long *)wm)[u]; starts += __builtin_popcountll(mk[u]); }
-            uint32_t pp[PANEL_UNROLL]; bool ok[PANEL_UNROLL]; int seg[PANEL_UNROLL];
+            for (int u = 0; u < PANEL_UNROLL; u++) {           // (a volatile read here compiles to a flat load that drains every load in flight)
+                mk[u] = __hip_atomic_load(&wm[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                starts += __builtin_popcountll(mk[u]);
+            }
             const uint32_t lastx = (uint32_t)((uint64_t)T - 1 - w0);      // last product of the window if it is the last window
+            int64_t pA[PANEL_UNROLL], pB[PANEL_UNROLL];
 #pragma unroll
             for (int u = 0; u < PANEL_UNROLL; u++) {
                 uint32_t x = (uint32_t)u * 64 + (uint32_t)lane;
                 ok[u] = w0 + x < (uint64_t)T;
                 if (!ok[u]) x = lastx;
+                ok[u] = ok[u] && real;
                 const int xu = (int)(x >> 6), xl = (int)(x & 63);
                 int cnt = 0;
 #pragma unroll
@@ -1049,23 +1075,29 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
                     const unsigned long long bits = (q < xu) ? ~0ull : ((q == xu) ? (~0ull >> (63 - xl)) : 0ull);
                     cnt += __builtin_popcountll(mk[q] & bits);
                 }
-                seg[u] = sb + cnt;
-                pp[u] = (uint32_t)(w0 + x);
-            }
-            int64_t pA[PANEL_UNROLL], pB[PANEL_UNROLL]; int32_t ii[PANEL_UNROLL];
-#pragma unroll
-            for (int u = 0; u < PANEL_UNROLL; u++) {
-                const unsigned long long w = S->where[seg[u]];
-                pA[u] = (int64_t)(w >> PANEL_T_BITS) + (int64_t)(pp[u] - S->off[seg[u]]);
+                const int seg = sb + cnt;
+                const unsigned long long w = S->where[seg];
+                pA[u] = (int64_t)(w >> PANEL_T_BITS) + (int64_t)((uint32_t)(w0 + x) - S->off[seg]);
                 pB[u] = pB0 + (int64_t)(w & (unsigned long long)(PANEL_MAX_DEG - 1));
             }
 #pragma unroll
             for (int u = 0; u < PANEL_UNROLL; u++) ii[u] = Ai[pA[u]];
-            decltype(load(ii[0], pA[0], pB[0])) payload[PANEL_UNROLL];
 #pragma unroll
-            for (int u = 0; u < PANEL_UNROLL; u++) payload[u] = load(ii[u], pA[u], pB[u]);
-            apply(ii, payload, ok);
-            if (!dynamic) { sb += starts + (edge ? 1 : 0); win++; }
+            for (int u = 0; u < PANEL_UNROLL; u++) raw[u] = load(ii[u], pA[u], pB[u]);
+            if (!dynamic) { sb += starts + (edge ? 1 : 0); win = real ? win + 1 : win_end; }
+            return real;
+        };
+        // two windows per wave in flight: the loads of one are issued before the other is consumed
+        int32_t iiA[PANEL_UNROLL], iiB[PANEL_UNROLL];
+        Raw rawA[PANEL_UNROLL], rawB[PANEL_UNROLL];
+        bool okA[PANEL_UNROLL], okB[PANEL_UNROLL];
+        bool liveA = stage(iiA, rawA, okA);
+        while (liveA) {
+            const bool liveB = stage(iiB, rawB, okB);
+            apply(iiA, rawA, okA);
+            if (!liveB) break;
+            liveA = stage(iiA, rawA, okA);
+            apply(iiB, rawB, okB);
         }
     }
     GBA_TICK(tke2);
@@ -1554,13 +1586,17 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
             GBA_TICK(tkp0);
             __syncthreads();
             panel_walk<NUM_PANEL_UNROLL>(A, B, pB0, deg, ibeg, pend, iend, first, pc, &Q,
-                [&](int32_t i, int64_t pA, int64_t pB) -> Z {
-                    return product(sr, A, B, apat, bpat, i, B.i[pB], j, pA, pB);
+                [&](int32_t, int64_t pA, int64_t pB) -> PanelOperands<S> {
+                    return fetch_operands(sr, A, B, apat, bpat, pA, pB);
                 },
-                [&](const int32_t (&i)[NUM_PANEL_UNROLL], const Z (&t)[NUM_PANEL_UNROLL], const bool (&ok)[NUM_PANEL_UNROLL]) {
+                [&](const int32_t (&i)[NUM_PANEL_UNROLL], const PanelOperands<S> (&r)[NUM_PANEL_UNROLL], const bool (&ok)[NUM_PANEL_UNROLL]) {
                     bool todo[NUM_PANEL_UNROLL];
+                    Z t[NUM_PANEL_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < NUM_PANEL_UNROLL; u++) todo[u] = ok[u] && mask_allows(M, i[u], j);
+                    for (int u = 0; u < NUM_PANEL_UNROLL; u++) {
+                        todo[u] = ok[u] && mask_allows(M, i[u], j);
+                        t[u] = sr.mult(r[u].a, r[u].b, (int64_t)i[u], r[u].k, j);
+                    }
                     if (direct) {
 #pragma unroll
                         for (int u = 0; u < NUM_PANEL_UNROLL; u++) if (todo[u]) {
@@ -1570,22 +1606,30 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                         }
                         return;
                     }
-                    // open addressing, linear probing
+                    // open addressing in buckets of four slots: one 16-byte LDS read shows a whole bucket, so a
+                    // product costs one or two dependent LDS operations instead of one per slot probed.  The
+                    // slots of a bucket fill in order and are never emptied before the emit, so two lanes with
+                    // the same index always meet in the same slot.
 #pragma unroll
                     for (int u = 0; u < NUM_PANEL_UNROLL; u++) if (todo[u]) {
                         const int32_t key = (int32_t)i[u];
-                        uint32_t h = panel_hash(key);
-                        bool placed = false;
+                        uint32_t hb = panel_hash(key) & ~3u;
+                        int slot = -1;
                         for (int probe = 0; probe < PANEL_PROBE_LIMIT; probe++) {
-                            const int32_t cur = keys[h];
-                            if (cur == key) { placed = true; break; }
-                            if (cur == HASH_EMPTY) {
-                                const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, key);
-                                if (old == HASH_EMPTY || old == key) { placed = true; break; }
+                            const int4 kk = *reinterpret_cast<const int4 *>(&keys[hb]);
+                            int pos = (kk.x == key) ? 0 : (kk.y == key) ? 1 : (kk.z == key) ? 2 : (kk.w == key) ? 3 : -1;
+                            if (pos < 0) {
+                                const int e = (kk.x == HASH_EMPTY) ? 0 : (kk.y == HASH_EMPTY) ? 1 : (kk.z == HASH_EMPTY) ? 2
+                                            : (kk.w == HASH_EMPTY) ? 3 : -1;
+                                if (e < 0) { hb = (hb + 4) & (NUM_PANEL_SLOTS - 1); continue; }     // bucket full: next one
+                                const int32_t old = atomicCAS(&keys[hb + e], HASH_EMPTY, key);
+                                if (old != HASH_EMPTY && old != key) continue;                      // lost the slot: look again
+                                pos = e;
                             }
-                            h = (h + 1) & (NUM_PANEL_SLOTS - 1);
+                            slot = (int)hb + pos;
+                            break;
                         }
-                        if (placed) sr.atomic(&vals[h], t[u]); else Q.overflow = 1;
+                        if (slot >= 0) sr.atomic(&vals[slot], t[u]); else Q.overflow = 1;
                     }
                 });
             if (Q.overflow) {                            // uniform: raised before the barrier that ended the walk
