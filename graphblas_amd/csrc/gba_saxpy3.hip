@@ -907,7 +907,7 @@ static constexpr int SYM_PANEL_WORDS = 24576;                         // 96 KiB 
 static constexpr int64_t SYM_PANEL_WIDTH = (int64_t)SYM_PANEL_WORDS * 32;
 static constexpr int NUM_PANEL_SLOTS = 8192;
 static constexpr int NUM_PANEL_TARGET = 3000;                         // distinct indices aimed at per panel (no boundaries known)
-static constexpr int NUM_PANEL_FIT = 4096;                            // entries between two recorded boundaries
+static constexpr int NUM_PANEL_FIT = 6144;                            // entries between two recorded boundaries
 static constexpr int SYM_WORDS_PER_THREAD = SYM_PANEL_WORDS / PANEL_THREADS;
 static constexpr int PANEL_PROBE_LIMIT = 48;
 static constexpr int64_t PANEL_INF = (int64_t)1 << 62;
@@ -1532,6 +1532,7 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
     ACC *vals = reinterpret_cast<ACC *>(smem);
     int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)NUM_PANEL_SLOTS * sizeof(ACC));
     unsigned long long st_panels = 0, st_overflows = 0;     // next[1], next[2]: panels swept / redone (reporting)
+    unsigned long long st_direct = 0, st_dent = 0, st_hent = 0;   // next[11..13]: direct panels, entries by kind of panel
     __shared__ PanelSegs Q;
     __shared__ int64_t row;
     __shared__ int out_cursor;
@@ -1668,6 +1669,7 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
             base = lim;
             shrink = 0;
             st_panels++;
+            if (direct) { st_direct++; st_dent += (unsigned long long)d; } else st_hent += (unsigned long long)d;
             if (d == 0) width = (width < cvlen) ? (width << 2) : width;
             else {
                 const int64_t covered = direct ? (int64_t)NUM_PANEL_SLOTS : width;
@@ -1680,7 +1682,10 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
             if (!more) break;
         }
     }
-    if (threadIdx.x == 0) { atomicAdd(&next[1], st_panels); atomicAdd(&next[2], st_overflows); }
+    if (threadIdx.x == 0) {
+        atomicAdd(&next[1], st_panels); atomicAdd(&next[2], st_overflows);
+        atomicAdd(&next[11], st_direct); atomicAdd(&next[12], st_dent); atomicAdd(&next[13], st_hent);
+    }
 #ifdef GBA_PANEL_TICKS
     if (threadIdx.x == 0) { Q.tk[7] = wall_clock64() - tkk; for (int q = 0; q < 8; q++) atomicAdd(&next[3 + q], Q.tk[q]); }
 #endif
@@ -1747,7 +1752,7 @@ struct Saxpy3Plan {
     void *team_Hx = nullptr; uint64_t *team_Hf = nullptr;
     const int64_t *bstart = nullptr;        // panel boundaries of vector j: bounds[bstart[j] .. bstart[j+1])
     int64_t *bounds = nullptr;
-    unsigned long long panel_stats[11] = {0};        // tasks pulled, panels swept, panels redone, stopwatch slots
+    unsigned long long panel_stats[14] = {0};        // tasks pulled, panels swept, panels redone, stopwatch slots [3..10], direct panels, entries of direct / hashed panels
 };
 
 template <class S>
@@ -1858,8 +1863,8 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         if (nblocks > ntasks) nblocks = ntasks;
         DevBuf scratch, next;
         GBA_OK(scratch.alloc((size_t)nblocks * PANEL_SCRATCH_ARRAYS * (size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
-        GBA_OK(next.alloc(96));
-        GBA_HIP(hipMemsetAsync(next.p, 0, 96, st));
+        GBA_OK(next.alloc(128));
+        GBA_HIP(hipMemsetAsync(next.p, 0, 128, st));
         auto k = num_panel_kernel<S>;
         const size_t lds = (size_t)NUM_PANEL_SLOTS * (sizeof(ACC) + 4);
         GBA_OK(set_lds(k, lds));
@@ -1868,8 +1873,11 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
                            scratch.as<int64_t>(), next.as<unsigned long long>(), P.Cp, P.Ci, Cx, P.bstart, P.bounds);
         GBA_HIP(hipGetLastError());
         mark(4);
-        GBA_HIP(hipMemcpyAsync(P.panel_stats, next.p, 88, hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipMemcpyAsync(P.panel_stats, next.p, 112, hipMemcpyDeviceToHost, st));
         GBA_HIP(hipStreamSynchronize(st));      // scratch is released on return
+        if (getenv("GBA_PANEL_PROF"))
+            fprintf(stderr, "[gba] numeric panels %llu (direct %llu), entries from direct panels %llu, from hashed panels %llu\n",
+                    P.panel_stats[1], P.panel_stats[11], P.panel_stats[12], P.panel_stats[13]);
     } else if (nb.count[BIN_GLOBAL] > 0) {
         const int64_t nf = (P.cvlen + 63) >> 6, ns = (nf + 63) >> 6;
         const size_t per_block = (size_t)P.cvlen * sizeof(ACC) + (size_t)(nf + ns) * 8;
