@@ -774,7 +774,7 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
         GBA_FAIL(GBA_DIMENSION_MISMATCH, "mask is %ld-by-%ld, output is %ld-by-%ld", (long)nrows(k.M), (long)ncols(k.M), (long)nrows(C), (long)ncols(C));
     const bool cast_T = C->type != k.semiring.ztype;          // T is cast to C's type before the write-back
     if (cast_T && (!is_real_type(C->type) || !is_real_type(k.semiring.ztype)))
-        GBA_FAIL(GBA_DOMAIN_MISMATCH, "C has type %d, the monoid %d", C->type, k.semiring.ztype);
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "C has type %d, the monoid %d (complex and user-defined types are not cast on the device)", C->type, k.semiring.ztype);
     if (k.has_accum && op_is_positional(k.accum.op)) GBA_FAIL(GBA_DOMAIN_MISMATCH, "positional accum");
 
     // mask shortcuts (Source/GB_mxm.c:105-114)

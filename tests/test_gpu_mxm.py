@@ -224,9 +224,11 @@ def test_errors_mirror_grb_info(gba):
     assert e.value.info == Info.DIMENSION_MISMATCH
     gba.mxm(C, None, None, "PLUS_TIMES_FP64", A, A, "T1")       # 10x12 * 12x10 is fine
     B = _rand(10, 10, 0.3, 10, t=Type.INT32).to_device()
+    rep = gba.mxm(C, None, None, "PLUS_TIMES_FP64", B, B, None)  # int32 operands are cast to the multiplier's fp64
+    assert rep.typecast == 3
     with pytest.raises(GrbError) as e:
-        gba.mxm(C, None, None, "PLUS_TIMES_FP64", B, B, None)   # needs a typecast: stays on the CPU library
-    assert e.value.info == Info.NOT_IMPLEMENTED
+        gba.mxm(C, None, None, gba.gba_semiring(gba.Op.PLUS, gba.Op.TIMES, Type.FC64, Type.FC64, Type.FC64), A, A, "T1")
+    assert e.value.info == Info.NOT_IMPLEMENTED                  # complex types stay on the CPU library
 
 
 def _operand(kind, n, A, rng, t):
