@@ -40,6 +40,9 @@ def parse():
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("GBA_BENCH_WATCHDOG"):                # a hang prints every thread's stack and ends the process
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["GBA_BENCH_WATCHDOG"]), exit=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
@@ -142,10 +145,11 @@ def main():
     fence()
     elapsed = time.perf_counter() - t1
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")      # gloo reduces host tensors
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        agg = torch.tensor([stats["cnz"]], dtype=torch.int64, device=dev)
+        agg = torch.tensor([stats["cnz"]], dtype=torch.int64, device=rdev)
         dist.all_reduce(agg)
         cnz_all = int(agg.item()) // max(args.steps, 1)
     else:

@@ -69,8 +69,17 @@ class RowBlockExchange:
             return
         c = self.counts[self.rank]
         self.si[:c] = my_i; self.sx[:c] = my_x
-        self.dist.all_gather(self.gi, self.si)
-        self.dist.all_gather(self.gx, self.sx)
+        if self.dist.get_backend() == "gloo" and self.si.is_cuda:
+            # gloo moves host memory: device tensors are staged through the host (CPU rehearsals of the path only;
+            # RCCL takes the device tensors as they are)
+            for send, recv in ((self.si, self.gi), (self.sx, self.gx)):
+                host = [self.torch.empty(self.pad, dtype=send.dtype) for _ in range(self.world)]
+                self.dist.all_gather(host, send.cpu())
+                for r in range(self.world):
+                    recv[r].copy_(host[r])
+        else:
+            self.dist.all_gather(self.gi, self.si)
+            self.dist.all_gather(self.gx, self.sx)
         for r in range(self.world):
             o, n = self.offs[r], self.counts[r]
             out_i[o: o + n] = self.gi[r][:n]
