@@ -1060,24 +1060,24 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
                 mk[u] = __hip_atomic_load(&wm[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 starts += __builtin_popcountll(mk[u]);
             }
-            const uint32_t lastx = (uint32_t)((uint64_t)T - 1 - w0);      // last product of the window if it is the last window
+            // a product's run = the window's first run + the starts marked at or before the product: the marks of
+            // the words before its own are counted once for all lanes, its own word takes one popcount.  Lanes
+            // past the last product (last window only) re-read the window's first product.
+            int pre[PANEL_UNROLL];
+            pre[0] = 0;
+#pragma unroll
+            for (int u = 1; u < PANEL_UNROLL; u++) pre[u] = pre[u - 1] + __builtin_popcountll(mk[u - 1]);
+            const unsigned long long upto = ~0ull >> (63 - lane);
             int64_t pA[PANEL_UNROLL], pB[PANEL_UNROLL];
 #pragma unroll
             for (int u = 0; u < PANEL_UNROLL; u++) {
-                uint32_t x = (uint32_t)u * 64 + (uint32_t)lane;
-                ok[u] = w0 + x < (uint64_t)T;
-                if (!ok[u]) x = lastx;
-                ok[u] = ok[u] && real;
-                const int xu = (int)(x >> 6), xl = (int)(x & 63);
-                int cnt = 0;
-#pragma unroll
-                for (int q = 0; q < PANEL_UNROLL; q++) {
-                    const unsigned long long bits = (q < xu) ? ~0ull : ((q == xu) ? (~0ull >> (63 - xl)) : 0ull);
-                    cnt += __builtin_popcountll(mk[q] & bits);
-                }
-                const int seg = sb + cnt;
+                const uint32_t x = (uint32_t)u * 64 + (uint32_t)lane;
+                const bool inside = w0 + x < (uint64_t)T;
+                ok[u] = inside && real;
+                const int seg = sb + (inside ? pre[u] + (int)__builtin_popcountll(mk[u] & upto) : 0);
+                const uint32_t pp = (uint32_t)w0 + (inside ? x : 0u);
                 const unsigned long long w = S->where[seg];
-                pA[u] = (int64_t)(w >> PANEL_T_BITS) + (int64_t)((uint32_t)(w0 + x) - S->off[seg]);
+                pA[u] = (int64_t)(w >> PANEL_T_BITS) + (int64_t)(pp - S->off[seg]);
                 pB[u] = pB0 + (int64_t)(w & (unsigned long long)(PANEL_MAX_DEG - 1));
             }
 #pragma unroll
