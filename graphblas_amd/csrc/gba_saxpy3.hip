@@ -899,7 +899,7 @@ static constexpr int PANEL_NPT = 2;                                   // neighbo
 static constexpr int PANEL_STEP = PANEL_THREADS * PANEL_NPT;
 static constexpr int PANEL_SEGCAP = 4 * PANEL_THREADS;                // runs queued in LDS before they are expanded
 static constexpr int PANEL_UNROLL_MAX = 8;
-static constexpr int SYM_PANEL_UNROLL = 2, NUM_PANEL_UNROLL = 2;            // products in flight per thread
+static constexpr int SYM_PANEL_UNROLL = 4, NUM_PANEL_UNROLL = 2;            // products in flight per thread
 static constexpr int PANEL_T_BITS = 24;
 static constexpr int64_t PANEL_MAX_DEG = (int64_t)1 << PANEL_T_BITS;
 static constexpr int64_t PANEL_MAX_WIDTH = (int64_t)1 << 20;          // (SEGCAP-1) runs of this length stay below 2^32
