@@ -1378,6 +1378,8 @@ bounds_room_kernel(int64_t nvec, const int64_t *__restrict__ vflops, int64_t cvl
 // pattern crosses every multiple of NUM_PANEL_FIT entries: bounds[bstart[j] + m - 1]
 // is one past the index of the (m * NUM_PANEL_FIT)-th entry of C(:,j).  Panels cut
 // at those indices fill the numeric table to exactly one half.
+// MASKED = false compiles the mask test away (the MaskView then costs no scalar registers either).
+template <bool MASKED>
 __global__ void __launch_bounds__(PANEL_THREADS)
 sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int64_t cvlen,
                  int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
@@ -1413,7 +1415,8 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                 [&](const int32_t (&i)[SYM_PANEL_UNROLL], const int (&)[SYM_PANEL_UNROLL], const bool (&ok)[SYM_PANEL_UNROLL]) {
 #pragma unroll
                     for (int u = 0; u < SYM_PANEL_UNROLL; u++) {
-                        if (!ok[u] || !mask_allows(M, i[u], j)) continue;
+                        if (!ok[u]) continue;
+                        if constexpr (MASKED) { if (!mask_allows(M, i[u], j)) continue; }
                         const uint32_t o = (uint32_t)(i[u] - base);
                         atomicOr(&bm[o >> 5], 1u << (o & 31));
                     }
@@ -1521,7 +1524,7 @@ panel_task_fill_kernel(int64_t nlist, const int64_t *__restrict__ list, const in
 __device__ inline uint32_t panel_hash(int32_t key) { return ((uint32_t)key * 0x9E3779B1u) >> 19; }
 static_assert(NUM_PANEL_SLOTS == (1 << 13), "panel_hash keeps the top 13 bits");
 
-template <class S>
+template <class S, bool MASKED>
 __global__ void __launch_bounds__(PANEL_THREADS)
 num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpView A, SpView B, MaskView M, int64_t cvlen,
                  int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
@@ -1595,7 +1598,8 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                     Z t[NUM_PANEL_UNROLL];
 #pragma unroll
                     for (int u = 0; u < NUM_PANEL_UNROLL; u++) {
-                        todo[u] = ok[u] && mask_allows(M, i[u], j);
+                        todo[u] = ok[u];
+                        if constexpr (MASKED) todo[u] = todo[u] && mask_allows(M, i[u], j);
                         t[u] = sr.mult(r[u].a, r[u].b, (int64_t)i[u], r[u].k, j);
                     }
                     if (direct) {
@@ -1865,7 +1869,7 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         GBA_OK(scratch.alloc((size_t)nblocks * PANEL_SCRATCH_ARRAYS * (size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
         GBA_OK(next.alloc(128));
         GBA_HIP(hipMemsetAsync(next.p, 0, 128, st));
-        auto k = num_panel_kernel<S>;
+        auto k = (P.M.kind == 0) ? num_panel_kernel<S, false> : num_panel_kernel<S, true>;
         const size_t lds = (size_t)NUM_PANEL_SLOTS * (sizeof(ACC) + 4);
         GBA_OK(set_lds(k, lds));
         hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
@@ -1945,10 +1949,11 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
         GBA_OK(next.alloc(8));
         GBA_HIP(hipMemsetAsync(next.p, 0, 8, st));
         const size_t lds = (size_t)SYM_PANEL_WORDS * 4;
-        GBA_OK(set_lds(sym_panel_kernel, lds));
+        auto k = (P.M.kind == 0) ? sym_panel_kernel<false> : sym_panel_kernel<true>;
+        GBA_OK(set_lds(k, lds));
         DevBuf order;
         GBA_OK(order_by_work_desc(sb.count[BIN_GLOBAL], sb.list(BIN_GLOBAL), P.vflops, &order));
-        hipLaunchKernelGGL(sym_panel_kernel, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
+        hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
                            sb.count[BIN_GLOBAL], order.as<int64_t>(), P.A, P.B, P.M, P.cvlen, P.maxdeg,
                            scratch.as<int64_t>(), next.as<unsigned long long>(), cnt, P.bstart, P.bounds);
         GBA_HIP(hipGetLastError());
