@@ -223,10 +223,13 @@ void     gba_matrix_free_content(gba_matrix *A);
  * may have been replaced (old ones freed with gba_free unless aliased with an
  * input) and its sparsity/jumbled/nzombies fields describe the result, exactly
  * as GB_mxm leaves its C (Source/GB_mxm.c:149-221).
+ * Operands and C of another built-in real type than the semiring's are cast
+ * (Source/GB_casting.h rules); hypersparse A, B, M and C are accepted and C
+ * comes back sparse.
  * Returns GBA_NOT_IMPLEMENTED for valid calls outside the device path
- * (user-defined ops, typecasts, hypersparse operands, ...): the caller keeps
- * the CPU library for those, like the GB_cuda_*_branch test in
- * Source/GB_AxB_dot.c:189-197. */
+ * (complex types, user-defined ops -- see gba_mxm_udt --, iso-valued C, ...):
+ * the caller keeps the CPU library for those, like the GB_cuda_*_branch test
+ * in Source/GB_AxB_dot.c:189-197. */
 gba_info gba_mxm(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
                  const gba_semiring *semiring, const gba_matrix *A, const gba_matrix *B,
                  const gba_descriptor *desc, gba_report *report);
