@@ -294,3 +294,39 @@ def test_rmat15_square_checksum_and_pattern(gba):
     assert got.nvals == want_nnz == got.p[-1]
     vec = np.repeat(np.arange(got.vdim), np.diff(got.p))
     assert len(np.unique(vec * got.vlen + got.i)) == got.nvals
+
+
+def test_rmat18_front_end_in_row_chunks_properties(gba):
+    """The bench's workload one size below the largest the host can still check entry by entry: C = A*A at
+    RMAT-18 (2.9e9 multiply-adds, 1.3e9 entries) through gba_mxm in flop-balanced row chunks, sorted on
+    request.  Size-independent properties per chunk: every row's sum equals (A (A 1)) for integer values
+    (exact in fp64), indices strictly increase inside a row (no duplicates, in range), row counts add up to
+    the multiply-add bound, and the entry count of the whole product matches the known value."""
+    from graphblas_amd import DeviceMatrix
+    from graphblas_amd.binding import gba_matrix
+    from graphblas_amd.dist import row_flops, chunks_by_flops
+    import graphblas_amd as g
+    A = gen.rmat(18, 16, seed=42, type=Type.FP64, values="int")            # CSR
+    n = A.nrows
+    S = sp.csr_matrix((A.x, A.i, A.p), shape=(n, n))
+    want_rowsum = S @ (S @ np.ones(n))
+    rf = row_flops(A.p, A.i)
+    prefix = np.concatenate([[0], np.cumsum(rf)]).astype(np.int64)
+    dA = A.to_device()
+    total = 0
+    for lo, hi in chunks_by_flops(prefix, 0, n, 400_000_000):
+        rows = dA.row_slice(lo, hi)
+        C = DeviceMatrix.empty(hi - lo, n, Type.FP64)
+        g.mxm(C, None, None, "PLUS_TIMES_FP64", rows, dA, g.descriptor(do_sort=1))
+        got = C.to_host(); C.free()
+        assert not got.jumbled and got.nzombies == 0
+        cnt = np.diff(got.p)
+        assert np.all(cnt <= rf[lo:hi]) and np.all((cnt > 0) == (rf[lo:hi] > 0))
+        assert got.i.min() >= 0 and got.i.max() < n
+        inner = np.ones(len(got.i), bool); inner[got.p[:-1][cnt > 0]] = False    # first entry of each row
+        assert np.all(np.diff(got.i)[inner[1:]] > 0), f"rows {lo}:{hi}: indices not strictly increasing"
+        sums = np.add.reduceat(got.x, got.p[:-1][cnt > 0])
+        assert np.array_equal(sums, want_rowsum[lo:hi][cnt > 0]), f"rows {lo}:{hi}: row sums differ"
+        total += int(got.p[-1])
+    dA.free()
+    assert total == 1282259348            # nnz (A*A) at RMAT-18, edge factor 16, seed 42 (the bench reports the same)
