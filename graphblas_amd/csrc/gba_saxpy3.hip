@@ -899,6 +899,8 @@ static constexpr int PANEL_NPT = 2;                                   // neighbo
 static constexpr int PANEL_STEP = PANEL_THREADS * PANEL_NPT;
 static constexpr int PANEL_SEGCAP = 4 * PANEL_THREADS;                // runs queued in LDS before they are expanded
 static constexpr int PANEL_UNROLL_MAX = 8;
+// two windows per wave in flight (the loads of one issued before the other is consumed)?
+static constexpr bool SYM_PANEL_PIPELINE = false, NUM_PANEL_PIPELINE = false;
 static constexpr int SYM_PANEL_UNROLL = 4, NUM_PANEL_UNROLL = 2;            // products in flight per thread
 static constexpr int PANEL_T_BITS = 24;
 static constexpr int64_t PANEL_MAX_DEG = (int64_t)1 << PANEL_T_BITS;
@@ -968,7 +970,7 @@ __device__ inline int64_t first_ge(const int32_t *__restrict__ X, int64_t lo, in
 // the runs are.  load(i, pA, pB) fetches what one product
 // needs; apply(i[], payload[], ok[]) consumes a batch of PANEL_UNROLL.  Needs a barrier between the last
 // append and the call; ends on a barrier with the queue empty.
-template <int PANEL_UNROLL, class Load, class Apply>
+template <int PANEL_UNROLL, bool PANEL_PIPELINE, class Load, class Apply>
 __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSegs *S, Load load, Apply apply) {
     static_assert(PANEL_SEGCAP == 4 * PANEL_THREADS && PANEL_SEGCAP <= 64 * 64, "four queue entries per thread in the scan; two 64-way steps find a run");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1023,8 +1025,9 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
             if (dynamic) {
                 if (lane == 0) win = atomicAdd(&S->wnext, 1u);
                 win = __shfl(win, 0, 64);
-                if (win >= nwin) { real = false; win = 0; }
+                if (win >= nwin) { if (!PANEL_PIPELINE) return false; real = false; win = 0; }
             } else if (win >= win_end) {
+                if (!PANEL_PIPELINE) return false;
                 real = false; win = 0; placed = false; sb = 0;
             }
             const uint64_t w0 = (uint64_t)win * WIN;
@@ -1091,6 +1094,9 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
         int32_t iiA[PANEL_UNROLL], iiB[PANEL_UNROLL];
         Raw rawA[PANEL_UNROLL], rawB[PANEL_UNROLL];
         bool okA[PANEL_UNROLL], okB[PANEL_UNROLL];
+        if constexpr (!PANEL_PIPELINE) {
+            while (stage(iiA, rawA, okA)) apply(iiA, rawA, okA);
+        } else {
         bool liveA = stage(iiA, rawA, okA);
         while (liveA) {
             const bool liveB = stage(iiB, rawB, okB);
@@ -1098,6 +1104,7 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
             if (!liveB) break;
             liveA = stage(iiA, rawA, okA);
             apply(iiB, rawB, okB);
+        }
         }
     }
     GBA_TICK(tke2);
@@ -1146,7 +1153,7 @@ __device__ inline void group_first_ge(const int32_t *__restrict__ X, bool act, i
 
 // panel_walk for a vector with few neighbours (deg * 2 <= PANEL_THREADS): their runs inside a panel are
 // long, so each neighbour gets a group of lanes that searches its list together (group_first_ge).
-template <int PANEL_UNROLL, class Load, class Apply>
+template <int PANEL_UNROLL, bool PANEL_PIPELINE, class Load, class Apply>
 __device__ inline void panel_walk_groups(const SpView &A, const SpView &B, int64_t pB0, int64_t deg, int64_t ibeg,
                                          int64_t pend, int64_t iend, bool first, const PanelCursors &pc, PanelSegs *S,
                                          Load load, Apply apply) {
@@ -1203,7 +1210,7 @@ __device__ inline void panel_walk_groups(const SpView &A, const SpView &B, int64
     GBA_TICK(tk2);
     GBA_TOCK(S, 0, tk0, tk1); GBA_TOCK(S, 1, tk1, tk2);
     const int ns = S->nseg;
-    if (ns > 0) panel_expand<PANEL_UNROLL>(A, pB0, ns, S, load, apply);
+    if (ns > 0) panel_expand<PANEL_UNROLL, PANEL_PIPELINE>(A, pB0, ns, S, load, apply);
     else __syncthreads();
 }
 
@@ -1215,12 +1222,12 @@ __device__ inline void panel_walk_groups(const SpView &A, const SpView &B, int64
 // expanded whenever it might not hold another step.  The caller provides a
 // barrier between resetting S->more / S->overflow and the call; the call ends
 // on a barrier.  Returns early (on a barrier) once S->overflow is raised.
-template <int PANEL_UNROLL, class Load, class Apply>
+template <int PANEL_UNROLL, bool PANEL_PIPELINE, class Load, class Apply>
 __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0, int64_t deg, int64_t ibeg,
                                   int64_t pend, int64_t iend, bool first, const PanelCursors &pc, PanelSegs *S,
                                   Load load, Apply apply) {
     if (deg * 2 <= PANEL_THREADS) {
-        panel_walk_groups<PANEL_UNROLL>(A, B, pB0, deg, ibeg, pend, iend, first, pc, S, load, apply);
+        panel_walk_groups<PANEL_UNROLL, PANEL_PIPELINE>(A, B, pB0, deg, ibeg, pend, iend, first, pc, S, load, apply);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1343,7 +1350,7 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
         const int ns = S->nseg;
         const bool last = t0 + PANEL_STEP >= deg;
         if (ns >= PANEL_SEGCAP - PANEL_STEP || (last && ns > 0)) {
-            panel_expand<PANEL_UNROLL>(A, pB0, ns, S, load, apply);
+            panel_expand<PANEL_UNROLL, PANEL_PIPELINE>(A, pB0, ns, S, load, apply);
             if (S->overflow) return;
         } else {
             __syncthreads();                                    // everyone has read nseg before the next append
@@ -1410,7 +1417,7 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
             const int64_t pend = (p == npanels - 1) ? PANEL_INF : base + SYM_PANEL_WIDTH;
             if (tid == 0) Q.more = 0;
             __syncthreads();
-            panel_walk<SYM_PANEL_UNROLL>(A, B, pB0, deg, 0, pend, PANEL_INF, p == 0, pc, &Q,
+            panel_walk<SYM_PANEL_UNROLL, SYM_PANEL_PIPELINE>(A, B, pB0, deg, 0, pend, PANEL_INF, p == 0, pc, &Q,
                 [](int32_t, int64_t, int64_t) { return 0; },
                 [&](const int32_t (&i)[SYM_PANEL_UNROLL], const int (&)[SYM_PANEL_UNROLL], const bool (&ok)[SYM_PANEL_UNROLL]) {
 #pragma unroll
@@ -1589,7 +1596,7 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
             if (threadIdx.x == 0) { Q.overflow = 0; Q.more = 0; out_cursor = 0; }
             GBA_TICK(tkp0);
             __syncthreads();
-            panel_walk<NUM_PANEL_UNROLL>(A, B, pB0, deg, ibeg, pend, iend, first, pc, &Q,
+            panel_walk<NUM_PANEL_UNROLL, NUM_PANEL_PIPELINE>(A, B, pB0, deg, ibeg, pend, iend, first, pc, &Q,
                 [&](int32_t, int64_t pA, int64_t pB) -> PanelOperands<S> {
                     return fetch_operands(sr, A, B, apat, bpat, pA, pB);
                 },
