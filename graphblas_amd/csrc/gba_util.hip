@@ -369,10 +369,13 @@ gba_info to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owne
 // them the sparse form of the same matrix (GB_convert_hyper_to_sparse, Source/GB_convert_hyper_to_sparse.c):
 // a pointer array over all vdim vectors, i and x shared with the original.
 __global__ void __launch_bounds__(256)
-hyper_scatter_kernel(int64_t nvec, const int64_t *__restrict__ h, const int64_t *__restrict__ p, int64_t *__restrict__ cnt) {
+hyper_scatter_kernel(int64_t nvec, int64_t vdim, const int64_t *__restrict__ h, const int64_t *__restrict__ p, int64_t *__restrict__ cnt) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; k < nvec; k += stride) cnt[h[k]] = p[k + 1] - p[k];
+    for (; k < nvec; k += stride) {
+        const int64_t j = h[k];
+        if ((unsigned long long)j < (unsigned long long)vdim) cnt[j] = p[k + 1] - p[k];      // a malformed list must not write outside
+    }
 }
 
 gba_info hyper_to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owned) {
@@ -387,7 +390,7 @@ gba_info hyper_to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *>
     if (nvec > 0) {
         if (!X->h || !X->p) GBA_FAIL(GBA_INVALID_OBJECT, "hypersparse matrix without h or p");
         int64_t blocks = ceil_div(nvec, 256); if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(hyper_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, X->h, X->p, Sp.as<int64_t>());
+        hipLaunchKernelGGL(hyper_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, vdim, X->h, X->p, Sp.as<int64_t>());
         GBA_HIP(hipGetLastError());
     }
     GBA_OK(dev_cumsum_i64(Sp.as<int64_t>(), vdim, st));
