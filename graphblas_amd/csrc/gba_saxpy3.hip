@@ -915,6 +915,7 @@ static constexpr int PANEL_PROBE_LIMIT = 48;
 static constexpr int64_t PANEL_INF = (int64_t)1 << 62;
 static constexpr int PANEL_SCRATCH_ARRAYS = 5;
 static_assert(SYM_PANEL_WIDTH <= PANEL_MAX_WIDTH, "symbolic panel too wide for 32-bit product offsets");
+static_assert((uint64_t)(PANEL_SEGCAP - 1) * PANEL_MAX_WIDTH + 64 * PANEL_UNROLL_MAX < (1ull << 32), "window ends fit 32 bits");
 static_assert(SYM_WORDS_PER_THREAD * PANEL_THREADS == SYM_PANEL_WORDS && SYM_WORDS_PER_THREAD * 32 < NUM_PANEL_FIT,
               "each thread owns a bitmap slice that can hold at most one boundary");
 
@@ -1030,28 +1031,28 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
                 if (!PANEL_PIPELINE) return false;
                 real = false; win = 0; placed = false; sb = 0;
             }
-            const uint64_t w0 = (uint64_t)win * WIN;
+            const uint32_t w0 = win * WIN;          // T + WIN < 2^32: 32-bit offsets throughout
             if (dynamic || !placed) {
                 // largest s with off[s] <= w0 (off[0] = 0), in two 64-way steps: every stride-th prefix sum,
                 // then the stride of them that brackets w0 (n <= 64 * 64)
                 const int stride = (n + 63) >> 6;
                 const int i1 = lane * stride;
-                const unsigned long long m1 = __ballot(i1 < n && (uint64_t)S->off[i1 < n ? i1 : 0] <= w0);
+                const unsigned long long m1 = __ballot(i1 < n && S->off[i1 < n ? i1 : 0] <= w0);
                 const int blk = (int)__builtin_popcountll(m1) - 1;
                 const int i2 = blk * stride + lane;
-                const unsigned long long m2 = __ballot(lane < stride && i2 < n && (uint64_t)S->off[i2 < n ? i2 : 0] <= w0);
+                const unsigned long long m2 = __ballot(lane < stride && i2 < n && S->off[i2 < n ? i2 : 0] <= w0);
                 sb = blk * stride + (int)__builtin_popcountll(m2) - 1;
                 placed = true;
             }
-            const uint64_t wend = w0 + WIN;
+            const uint32_t wend = w0 + WIN;
             if (lane < PANEL_UNROLL) wm[lane] = 0ull;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             bool edge = false;                          // a run starts exactly at the next window
             for (int cursor = sb + 1;; cursor += 64) {
                 const int idx = cursor + lane;
-                const uint64_t o = (idx < n) ? (uint64_t)S->off[idx] : ~0ull;
+                const uint32_t o = (idx < n) ? S->off[idx] : ~0u;
                 const bool in = o < wend;               // off[] is strictly increasing and off[sb + 1] > w0
-                if (in) { const uint32_t q = (uint32_t)(o - w0); atomicOr(&wm[q >> 6], 1ull << (q & 63)); }
+                if (in) { const uint32_t q = o - w0; atomicOr(&wm[q >> 6], 1ull << (q & 63)); }
                 if (__ballot(o == wend)) edge = true;
                 if (__ballot(in) != ~0ull) break;
             }
@@ -1075,10 +1076,10 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
 #pragma unroll
             for (int u = 0; u < PANEL_UNROLL; u++) {
                 const uint32_t x = (uint32_t)u * 64 + (uint32_t)lane;
-                const bool inside = w0 + x < (uint64_t)T;
+                const bool inside = w0 + x < T;
                 ok[u] = inside && real;
                 const int seg = sb + (inside ? pre[u] + (int)__builtin_popcountll(mk[u] & upto) : 0);
-                const uint32_t pp = (uint32_t)w0 + (inside ? x : 0u);
+                const uint32_t pp = w0 + (inside ? x : 0u);
                 const unsigned long long w = S->where[seg];
                 pA[u] = (int64_t)(w >> PANEL_T_BITS) + (int64_t)(pp - S->off[seg]);
                 pB[u] = pB0 + (int64_t)(w & (unsigned long long)(PANEL_MAX_DEG - 1));
