@@ -309,10 +309,19 @@ cast_kernel(int64_t n, const From *__restrict__ x, To *__restrict__ z) {
 // X with its values in another built-in type: a new x array, the pattern arrays shared
 // (what GB_GETA / GB_cast_matrix do entry by entry on the CPU, Source/GB_cast_matrix.c)
 static gba_info cast_values(const gba_matrix *X, int to_type, gba_matrix *out, std::vector<void *> &owned) {
-    const int64_t n = X->iso ? 1 : (is_dense_fmt(X) ? X->vlen * X->vdim : nnz_held(X));
+    // a sparse view may start in the middle of its arrays (a row slice keeps the absolute offsets in p): the
+    // entries are x[p[0] .. p[nvec])
+    int64_t p0 = 0, n = X->iso ? 1 : (is_dense_fmt(X) ? X->vlen * X->vdim : nnz_held(X));
+    if (!X->iso && !is_dense_fmt(X) && X->p) {
+        int64_t pend = 0;
+        GBA_OK(dev_read_i64(X->p, &p0));
+        GBA_OK(dev_read_i64(X->p + X->nvec, &pend));
+        n = pend - p0;
+    }
     void *z = gba_malloc((size_t)(n > 0 ? n : 1) * esize_of(to_type));
     if (!z) GBA_FAIL(GBA_OUT_OF_MEMORY, "typecast of %ld values", (long)n);
     owned.push_back(z);
+    const uint8_t *xsrc = reinterpret_cast<const uint8_t *>(X->x) + (size_t)p0 * esize_of(X->type);
     if (n > 0 && X->x) {
         int64_t blocks = ceil_div(n, 256); if (blocks > 8192) blocks = 8192;
         GBA_OK(with_type(to_type, [&](auto to) -> gba_info {
@@ -320,14 +329,15 @@ static gba_info cast_values(const gba_matrix *X, int to_type, gba_matrix *out, s
             return with_type(X->type, [&](auto from) -> gba_info {
                 using From = decltype(from);
                 hipLaunchKernelGGL((cast_kernel<To, From>), dim3((unsigned)blocks), dim3(256), 0, ctx().stream, n,
-                                   reinterpret_cast<const From *>(X->x), reinterpret_cast<To *>(z));
+                                   reinterpret_cast<const From *>(xsrc), reinterpret_cast<To *>(z));
                 return GBA_SUCCESS;
             });
         }));
         GBA_HIP(hipGetLastError());
     }
     *out = *X;
-    out->x = z; out->type = to_type;
+    out->x = reinterpret_cast<uint8_t *>(z) - (size_t)p0 * esize_of(to_type);     // indexed by the same absolute offsets as X->x
+    out->type = to_type;
     return GBA_SUCCESS;
 }
 
@@ -585,7 +595,7 @@ static void free_unaliased(gba_matrix *C, const Call &k) {
         if (!q) return true;
         const gba_matrix *ins[3] = {k.M, k.A_in, k.B_in};
         for (const gba_matrix *X : ins) {
-            if (!X) continue;
+            if (!X || X == C) continue;             // C handed in as its own operand or mask: nobody else holds its arrays
             if (q == X->p || q == X->i || q == X->x || q == X->b || q == X->h) return true;
         }
         return false;

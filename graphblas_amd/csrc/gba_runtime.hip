@@ -334,14 +334,22 @@ gba_info stage_to_device(const gba_matrix *in, gba_matrix *out, std::vector<void
         return GBA_SUCCESS;
     };
     const size_t xs = type_size(in->type);
-    const int64_t held = nnz_held(in);
     const int64_t dense = in->vlen * in->vdim;
+    // a sparse view may start in the middle of its arrays (a row slice keeps the absolute offsets in p): only
+    // the entries p[0] .. p[nvec) travel, and the device arrays are addressed by the same offsets
+    int64_t e0 = 0, held = nnz_held(in);
+    if (!is_dense_fmt(in) && in->p) { e0 = in->p[0]; held = in->p[in->nvec] - e0; }
     GBA_OK(up(in->p, (size_t)(in->nvec + 1) * 8, (void **)&out->p));
     GBA_OK(up(in->h, (size_t)in->nvec * 8, (void **)&out->h));
-    GBA_OK(up(in->i, (size_t)in->nvals * 8, (void **)&out->i));
+    GBA_OK(up(in->i ? in->i + e0 : nullptr, (size_t)held * 8, (void **)&out->i));
+    if (out->i) out->i -= e0;
     GBA_OK(up(in->b, (size_t)dense, (void **)&out->b));
-    const int64_t nx = in->iso ? 1 : (is_dense_fmt(in) ? dense : held);
-    GBA_OK(up(in->x, (size_t)nx * xs, &out->x));
+    if (in->iso || is_dense_fmt(in)) {
+        GBA_OK(up(in->x, (size_t)(in->iso ? 1 : dense) * xs, &out->x));
+    } else {
+        GBA_OK(up(in->x ? reinterpret_cast<const uint8_t *>(in->x) + (size_t)e0 * xs : nullptr, (size_t)held * xs, &out->x));
+        if (out->x) out->x = reinterpret_cast<uint8_t *>(out->x) - (size_t)e0 * xs;
+    }
     GBA_HIP(hipStreamSynchronize(st));
     out->mem = GBA_MEM_DEVICE;
     return GBA_SUCCESS;

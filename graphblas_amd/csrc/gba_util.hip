@@ -434,7 +434,12 @@ gba_info transpose(gba_matrix *AT, const gba_matrix *A) {
     if (A->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "transpose: zombies");
     if (A->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_NOT_IMPLEMENTED, "transpose of a host view");
     hipStream_t st = ctx().stream;
-    const int64_t anz = A->nvals, tvec = A->vlen, avec = A->nvec;
+    // a view may start in the middle of its arrays (a row slice keeps the absolute offsets in p): its entries
+    // are i[p[0] .. p[nvec])
+    int64_t a0 = 0, aend = 0;
+    GBA_OK(dev_read_i64(A->p, &a0));
+    GBA_OK(dev_read_i64(A->p + A->nvec, &aend));
+    const int64_t anz = aend - a0, tvec = A->vlen, avec = A->nvec;
     const int esize = (int)esize_of(A->type);
     DevBuf Tp, Ti, Tx, cur;
     GBA_OK(Tp.alloc((size_t)(tvec + 1) * 8));
@@ -444,7 +449,7 @@ gba_info transpose(gba_matrix *AT, const gba_matrix *A) {
     GBA_HIP(hipMemsetAsync(Tp.p, 0, (size_t)(tvec + 1) * 8, st));
     if (anz > 0) {
         int64_t blocks = ceil_div(anz, 256); if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(transpose_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, anz, A->i, Tp.as<unsigned long long>());
+        hipLaunchKernelGGL(transpose_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, anz, A->i + a0, Tp.as<unsigned long long>());
     }
     GBA_OK(dev_cumsum_i64(Tp.as<int64_t>(), tvec, st));
     GBA_HIP(hipMemcpyAsync(cur.p, Tp.p, (size_t)(tvec + 1) * 8, hipMemcpyDeviceToDevice, st));

@@ -285,3 +285,61 @@ def _select_vec(gba, call, w, mask, accum, sr, A, u, desc):
     if call == "mxv":
         return gba.mxv(wc, mask, accum, sr, A, u if u is not w else wc, desc)
     return gba.vxm(wc, mask, accum, sr, u if u is not w else wc, A, desc)
+
+
+@pytest.mark.parametrize("case", ["T0", "cast", "host"])
+def test_row_slice_views_that_keep_absolute_offsets(gba, case):
+    """A row slice of a sparse matrix is a view whose p keeps the absolute positions (p[0] != 0).  The paths that
+    walk the entries of an operand directly -- the explicit transpose behind a descriptor transpose, the
+    typecast of an operand, the staging of a host view -- must take entries p[0] .. p[nvec), not 0 .. nvals."""
+    n, lo, hi = 90, 31, 77
+    t = Type.FP32 if case == "cast" else Type.FP64
+    A = _rand(n, n, 0.15, 11, t=t)
+    B = _rand(hi - lo if case == "T0" else n, n, 0.12, 12)
+    S = A.to_scipy()[lo:hi]
+    Asub = Matrix.from_scipy(S.astype(NP_TYPES[t]), type=t)
+    desc = "T0" if case == "T0" else ""
+    C0 = Matrix.sparse_empty(n if case == "T0" else hi - lo, n, Type.FP64)
+    p, v = oracle.mxm_spec(C0, None, None, "PLUS_TIMES_FP64", Asub, B, desc)
+    dB, dC = B.to_device(), C0.to_device()
+    if case == "host":
+        import ctypes
+
+        class HostView:                                     # gba_matrix over host arrays (mem = host), p not rebased
+            def __init__(self, M):
+                self.keep = []
+                self.v = M.view(self.keep)
+
+            def ref(self):
+                return ctypes.byref(self.v)
+
+        hv = HostView(Matrix(A.vlen, hi - lo, t, A.sparsity, A.is_csc, p=A.p[lo:hi + 1], i=A.i, x=A.x,
+                             nvals=int(A.p[hi] - A.p[lo])))
+        gba.mxm(dC, None, None, "PLUS_TIMES_FP64", hv, dB, desc)
+    else:
+        dA = A.to_device()
+        gba.mxm(dC, None, None, "PLUS_TIMES_FP64", dA.row_slice(lo, hi), dB, desc)
+    assert_dense_same(dC.to_host(), p, v, exact=True, what=case)
+
+
+def test_output_that_is_its_own_operand_does_not_leak(gba):
+    """C = C*B, and q<!v> = q*A of a traversal: the arrays C held before the call belong to nobody else and
+    must go back to the pool (Source/GB_mxm.c:48 allows the aliasing)."""
+    import ctypes
+    n = 300
+    B = _rand(n, n, 0.02, 21)
+    Cm = _rand(n, n, 0.02, 22)
+    dB, dC = B.to_device(), Cm.to_device()
+    want = Cm.to_scipy()
+    live = []
+    for _ in range(6):
+        gba.mxm(dC, None, None, "PLUS_TIMES_FP64", dC, dB, "")
+        want = want @ B.to_scipy()
+        idle, lv = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        gba.lib.gba_pool_stats(ctypes.byref(idle), ctypes.byref(lv))
+        live.append(lv.value)
+    got = dC.to_host().to_scipy()
+    assert abs(got - want).max() <= 1e-9 * abs(want).max()
+    # the product fills in, so C itself grows; what must not grow is one old copy of C per call
+    sizes = np.diff(live)
+    assert live[-1] - live[0] < 4 * (got.nnz * 16 + (n + 1) * 8), (live, got.nnz)
