@@ -643,6 +643,10 @@ static gba_info run_dot(gba_matrix *T, const Call &k, const gba_matrix *C_in, co
                         const gba_matrix *A, const gba_matrix *B, bool flipxy, Exec &ex, bool select_only) {
     Canon c;
     GBA_OK(canonicalize(&k.semiring, flipxy, A->type, B->type, &c));
+    // the dot methods merge sorted lists (GB_MATRIX_WAIT_IF_JUMBLED on A and B, Source/GB_AxB_dot.c:78-87)
+    gba_matrix Asorted, Bsorted;
+    if (!select_only && is_sparse(A) && A->jumbled) { GBA_OK(sorted_copy(A, &Asorted, ex.owned)); A = &Asorted; }
+    if (!select_only && is_sparse(B) && B->jumbled) { GBA_OK(sorted_copy(B, &Bsorted, ex.owned)); B = &Bsorted; }
     const bool C_iso = axb_iso(A, B, k.semiring, flipxy);
     if (C_iso && A->iso && as_if_full(A) && B->iso && as_if_full(B)) ex.rep.method = GBA_METHOD_ISO_FULL;
     if (dot4_control(C_iso, C_in, M, k.Mask_comp, k) && c.add != GBA_ANY &&
@@ -767,6 +771,14 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
         if (b_read && B_in->type != b_want && is_real_type(B_in->type) && is_real_type(b_want) && !select_only) {
             GBA_OK(cast_values(B_in, b_want, &Bcast, ex.owned)); k.B_in = B_in = &Bcast; ex.rep.typecast |= 2;
         }
+    }
+    // pending work of the inputs is finished on copies (GB_MATRIX_WAIT, Source/GB_mxm.c:105-116): zombies are
+    // removed, and a jumbled mask is sorted; jumbled A and B are sorted only where a dot method needs it (run_dot)
+    gba_matrix Mw, Aw, Bw;
+    if (!select_only) {
+        if (k.M && is_sparse(k.M) && (k.M->nzombies || k.M->jumbled)) { GBA_OK(sorted_copy(k.M, &Mw, ex.owned)); k.M = &Mw; }
+        if (is_sparse(A_in) && A_in->nzombies) { GBA_OK(sorted_copy(A_in, &Aw, ex.owned)); k.A_in = A_in = &Aw; }
+        if (is_sparse(B_in) && B_in->nzombies) { GBA_OK(sorted_copy(B_in, &Bw, ex.owned)); k.B_in = B_in = &Bw; }
     }
     if (A_in->nzombies || B_in->nzombies || (k.M && k.M->nzombies))
         GBA_FAIL(GBA_INVALID_OBJECT, "inputs with zombies: call gba_matrix_wait first (Source/GB_mxm.c:105-116)");

@@ -286,6 +286,49 @@ gba_info matrix_wait(gba_matrix *C) {
     return GBA_SUCCESS;
 }
 
+// A sorted copy of a sparse matrix, free of zombies: what the reference obtains by finishing the pending work
+// of its inputs inside the call (GB_MATRIX_WAIT, Source/GB_mxm.c:105-116; GB_MATRIX_WAIT_IF_JUMBLED,
+// Source/GB_AxB_dot.c:78-87).  The caller's matrix is left as it is.
+__global__ void __launch_bounds__(256)
+rebase_pointers_kernel(int64_t n, const int64_t *__restrict__ in, int64_t base, int64_t *__restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < n; k += stride) out[k] = in[k] - base;
+}
+
+gba_info sorted_copy(const gba_matrix *X, gba_matrix *out, std::vector<void *> &owned) {
+    GBA_OK(require_init());
+    if (!is_sparse(X)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "sorted copy of a matrix with sparsity %d", X->sparsity);
+    if (X->iso) GBA_FAIL(GBA_NOT_IMPLEMENTED, "jumbled iso-valued operand");
+    hipStream_t st = ctx().stream;
+    const size_t esize = esize_of(X->type);
+    int64_t p0 = 0, pend = 0;
+    GBA_OK(dev_read_i64(X->p, &p0));
+    GBA_OK(dev_read_i64(X->p + X->nvec, &pend));
+    const int64_t n = pend - p0;
+    DevBuf Np, Ni, Nx;
+    GBA_OK(Np.alloc((size_t)(X->nvec + 1) * 8));
+    GBA_OK(Ni.alloc((size_t)(n > 0 ? n : 1) * 8));
+    GBA_OK(Nx.alloc((size_t)(n > 0 ? n : 1) * (esize ? esize : 1)));
+    int64_t blocks = ceil_div(X->nvec + 1, 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rebase_pointers_kernel, dim3((unsigned)blocks), dim3(256), 0, st, X->nvec + 1, X->p, p0, Np.as<int64_t>());
+    GBA_HIP(hipGetLastError());
+    if (n > 0) {
+        GBA_HIP(hipMemcpyAsync(Ni.p, X->i + p0, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        if (X->x) GBA_HIP(hipMemcpyAsync(Nx.p, reinterpret_cast<const uint8_t *>(X->x) + (size_t)p0 * esize, (size_t)n * esize, hipMemcpyDeviceToDevice, st));
+    }
+    gba_matrix T = *X;
+    T.p = reinterpret_cast<int64_t *>(Np.release());
+    T.i = reinterpret_cast<int64_t *>(Ni.release());
+    T.x = Nx.release();
+    T.h = nullptr; T.b = nullptr; T.nvals = n; T.mem = GBA_MEM_DEVICE;
+    gba_info info = matrix_wait(&T);                // removes zombies (new arrays) and sorts every vector
+    owned.push_back(T.p); owned.push_back(T.i); owned.push_back(T.x);
+    if (info != GBA_SUCCESS) return info;
+    *out = T;
+    return GBA_SUCCESS;
+}
+
 // -------------------------------------------------------- bitmap/full -> sparse --
 // GB_convert_bitmap_to_sparse / GB_convert_full_to_sparse (Source/GB_convert_bitmap_to_sparse.c,
 // GB_convert_full_to_sparse.c): same orientation, entries in index order.  One wavefront per vector.

@@ -343,3 +343,30 @@ def test_output_that_is_its_own_operand_does_not_leak(gba):
     # the product fills in, so C itself grows; what must not grow is one old copy of C per call
     sizes = np.diff(live)
     assert live[-1] - live[0] < 4 * (got.nnz * 16 + (n + 1) * 8), (live, got.nnz)
+
+
+def test_jumbled_results_feed_the_next_call(gba):
+    """Every sparse product comes back jumbled (as the reference leaves it).  Used as the mask or as a dot-product
+    operand of the next call it is sorted inside the call, on a copy (GB_MATRIX_WAIT, Source/GB_mxm.c:105-116;
+    GB_MATRIX_WAIT_IF_JUMBLED, Source/GB_AxB_dot.c:78-87) -- the caller need not wait on it first."""
+    n = 120
+    A, B = _rand(n, n, 0.06, 31), _rand(n, n, 0.06, 32)
+    dA, dB = A.to_device(), B.to_device()
+    d1 = DeviceMatrix.empty(n, n, Type.FP64)
+    gba.mxm(d1, None, None, "PLUS_TIMES_FP64", dA, dA, "")
+    C1 = d1.to_host()
+    assert C1.jumbled
+    # jumbled mask of a saxpy product
+    C0 = Matrix.sparse_empty(n, n, Type.FP64)
+    d2 = C0.to_device()
+    gba.mxm(d2, d1, None, "PLUS_TIMES_FP64", dB, dB, "S")
+    p, v = oracle.mxm_spec(C0, C1, None, "PLUS_TIMES_FP64", B, B, "S")
+    assert_dense_same(d2.to_host(), p, v, exact=True, what="jumbled mask")
+    # jumbled operand of a masked dot product (C<M,struct> = A*B' takes dot3, like the triangle count)
+    M = _rand(n, n, 0.3, 33, t=Type.INT8, lo=1, hi=2)
+    d3 = C0.to_device()
+    rep = gba.mxm(d3, M.to_device(), None, "PLUS_TIMES_FP64", dB, d1, "ST1")
+    assert Method.NAMES[rep.method] == "dot3"
+    p, v = oracle.mxm_spec(C0, M, None, "PLUS_TIMES_FP64", B, C1, "ST1")
+    assert_dense_same(d3.to_host(), p, v, exact=True, what="jumbled dot operand")
+    assert d1.to_host().jumbled                              # the caller's matrix is untouched
