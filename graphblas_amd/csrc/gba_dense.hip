@@ -275,7 +275,7 @@ static gba_info dot_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask_c
     if (A->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "dot: A has zombies");
     hipStream_t st = ctx().stream;
     const int64_t cvlen = A->vdim, cvdim = B->vdim;
-    if (cvdim > 65535) GBA_FAIL(GBA_NOT_IMPLEMENTED, "dot: more than 65535 dense vectors");
+    if (cvdim > 65535) GBA_FAIL(GBA_NO_VALUE, "dot: more than 65535 dense vectors (declined: the caller takes the general path)");
     MaskViewD mv; GBA_OK(make_maskd(M, Mask_comp, Mask_struct, &mv));
     DevBuf Cb, Cx;
     const size_t zsize = type_size(c.ztype);
@@ -419,7 +419,7 @@ static gba_info saxpy_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask
     if (A->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "saxpy: A has zombies");
     hipStream_t st = ctx().stream;
     const int64_t cvlen = A->vlen, cvdim = B->vdim;
-    if (cvdim > 65535) GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxpy: more than 65535 dense vectors");
+    if (cvdim > 65535) GBA_FAIL(GBA_NO_VALUE, "saxpy: more than 65535 dense vectors (declined: the caller takes the general path)");
     const int64_t cn = cvlen * cvdim;
     MaskViewD mv; GBA_OK(make_maskd(M, Mask_comp, Mask_struct, &mv));
     if (MODE == 0) {
@@ -582,7 +582,7 @@ gba_info saxpy5(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const C
     const int64_t cvlen = A->vlen, cvdim = B->vdim;
     if (!is_full(C) || C->type != c.ztype || C->vlen != cvlen || C->vdim != cvdim || C->iso)
         GBA_FAIL(GBA_INVALID_VALUE, "saxpy5: C must be a full non-iso matrix of the monoid type");
-    if (cvdim > 65535) GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxpy5: more than 65535 vectors in B");
+    if (cvdim > 65535) GBA_FAIL(GBA_NO_VALUE, "saxpy5: more than 65535 vectors in B (declined: the caller takes the general path)");
     hipStream_t st = ctx().stream;
     KernelTimer timer(rep != nullptr);
     if (cvlen > 0 && cvdim > 0) {

@@ -28,10 +28,12 @@ struct Context {
     int device = -1;
     hipStream_t stream = nullptr;
     int num_cu = 256;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;        // KernelTimer (inside the library)
+    hipEvent_t tm0 = nullptr, tm1 = nullptr;        // gba_timer_start / gba_timer_stop (the caller's stopwatch)
 };
 Context &ctx();
 gba_info require_init();
+void jit_unload_all();          // gba_jit.hip: unload every hipRTC module (gba_finalize)
 // bytes per entry of a matrix, user-defined types included
 inline size_t esize_of(int type) { return type == GBA_UDT ? ctx().udt_size : type_size(type); }
 

@@ -25,6 +25,13 @@ static std::map<std::string, JitKernels> g_jit_cache;
 #define GBA_RTC(call) do { hiprtcResult r_ = (call); if (r_ != HIPRTC_SUCCESS) \
     GBA_FAIL(GBA_PANIC, "%s -> %s", #call, hiprtcGetErrorString(r_)); } while (0)
 
+// gba_finalize: the compiled modules go with the device context they were loaded into
+void jit_unload_all() {
+    std::lock_guard<std::mutex> lock(g_jit_mu);
+    for (auto &e : g_jit_cache) hipModuleUnload(e.second.module);
+    g_jit_cache.clear();
+}
+
 static std::string device_function(const char *defn) {
     // "void f (T *z, const T *x, const T *y) { ... }"  ->  a __device__ function
     return std::string("__device__ inline ") + defn + "\n";
@@ -79,7 +86,8 @@ static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, co
         "}\n";
 
     std::lock_guard<std::mutex> lock(g_jit_mu);
-    auto it = g_jit_cache.find(src);
+    const std::string key = std::to_string(ctx().device) + "\n" + src;      // modules belong to the device they were loaded on
+    auto it = g_jit_cache.find(key);
     if (it != g_jit_cache.end()) { *out = it->second; return GBA_SUCCESS; }
 
     hiprtcProgram prog;
@@ -104,7 +112,7 @@ static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, co
     GBA_HIP(hipModuleLoadData(&k.module, code.data()));
     GBA_HIP(hipModuleGetFunction(&k.dot, k.module, "gba_udt_dot"));
     GBA_HIP(hipModuleGetFunction(&k.accum, k.module, "gba_udt_accum"));
-    g_jit_cache[src] = k;
+    g_jit_cache[key] = k;
     *out = k;
     return GBA_SUCCESS;
 }

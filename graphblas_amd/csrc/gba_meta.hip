@@ -665,7 +665,10 @@ static gba_info run_dot(gba_matrix *T, const Call &k, const gba_matrix *C_in, co
     ex.rep.method = GBA_METHOD_DOT2;
     ex.mask_applied = (M != nullptr);
     if (select_only) return GBA_SUCCESS;
-    if (is_sparse(A) && is_dense_fmt(B)) return dot2(T, M, k.Mask_comp, k.Mask_struct, A, B, c, &ex.rep);
+    if (is_sparse(A) && is_dense_fmt(B)) {
+        gba_info info = dot2(T, M, k.Mask_comp, k.Mask_struct, A, B, c, &ex.rep);
+        if (info != GBA_NO_VALUE) return info;          // declined (more dense vectors than one grid takes): general path
+    }
     { const int method = ex.rep.method; gba_info info = general_saxpy3(T, k, M, A, true, B, c, ex); ex.rep.method = method; return info; }
 }
 
@@ -718,7 +721,10 @@ static gba_info run_saxpy(gba_matrix *T, const Call &k, const gba_matrix *C_in, 
     ex.rep.method = GBA_METHOD_SAXBIT;
     ex.mask_applied = (M != nullptr);
     if (select_only) return GBA_SUCCESS;
-    if ((is_sparse(A) || is_dense_fmt(A)) && is_dense_fmt(B)) return saxbit(T, M, k.Mask_comp, k.Mask_struct, A, B, c, &ex.rep);
+    if ((is_sparse(A) || is_dense_fmt(A)) && is_dense_fmt(B)) {
+        gba_info info = saxbit(T, M, k.Mask_comp, k.Mask_struct, A, B, c, &ex.rep);
+        if (info != GBA_NO_VALUE) return info;
+    }
     { gba_info info = general_saxpy3(T, k, M, A, false, B, c, ex); ex.rep.method = GBA_METHOD_SAXBIT; return info; }
 }
 

@@ -457,6 +457,8 @@ gba_info gba_init(int device) {
     GBA_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     GBA_HIP(hipEventCreate(&c.ev0));
     GBA_HIP(hipEventCreate(&c.ev1));
+    GBA_HIP(hipEventCreate(&c.tm0));
+    GBA_HIP(hipEventCreate(&c.tm1));
     c.device = device;
     c.inited = true;
     size_t free_b = 0, total_b = 0;
@@ -470,8 +472,11 @@ gba_info gba_finalize(void) {
     if (!c.inited) return GBA_SUCCESS;
     hipStreamSynchronize(c.stream);
     pool().release_all();
+    jit_unload_all();
     hipEventDestroy(c.ev0);
     hipEventDestroy(c.ev1);
+    hipEventDestroy(c.tm0);
+    hipEventDestroy(c.tm1);
     hipStreamDestroy(c.stream);
     c = Context();
     return GBA_SUCCESS;
@@ -521,15 +526,15 @@ void *gba_stream(void) { return (void *)ctx().stream; }
 
 gba_info gba_timer_start(void) {
     GBA_OK(require_init());
-    GBA_HIP(hipEventRecord(ctx().ev0, ctx().stream));
+    GBA_HIP(hipEventRecord(ctx().tm0, ctx().stream));
     return GBA_SUCCESS;
 }
 gba_info gba_timer_stop(double *ms) {
     GBA_OK(require_init());
-    GBA_HIP(hipEventRecord(ctx().ev1, ctx().stream));
-    GBA_HIP(hipEventSynchronize(ctx().ev1));
+    GBA_HIP(hipEventRecord(ctx().tm1, ctx().stream));
+    GBA_HIP(hipEventSynchronize(ctx().tm1));
     float f = 0.f;
-    GBA_HIP(hipEventElapsedTime(&f, ctx().ev0, ctx().ev1));
+    GBA_HIP(hipEventElapsedTime(&f, ctx().tm0, ctx().tm1));
     if (ms) *ms = (double)f;
     return GBA_SUCCESS;
 }

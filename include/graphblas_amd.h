@@ -131,7 +131,8 @@ typedef struct gba_matrix {
 #define GBA_FLIP(i) (-(i) - 2)          /* Source/Template/GB_zombie.h */
 
 /* built-in semiring: z = add-reduce over k of mult(x = A(i,k), y = B(k,j)).
- * User-defined operators are GBA_USER_BINOP and are declined. */
+ * gba_mxm / gba_mxv / gba_vxm take built-in operators only; user-defined types and
+ * operators (GBA_USER_BINOP) go through gba_mxm_udt, which compiles them with hipRTC. */
 typedef struct gba_semiring {
     gba_opcode add;      /* monoid operator; its type is ztype            */
     gba_opcode mult;
@@ -288,9 +289,13 @@ gba_info gba_mxm_select(const gba_matrix *C, const gba_matrix *M, const gba_bino
  * (C->type must be set to the semiring's ztype). */
 
 /* C<#M> = A*B, C sparse: GB_AxB_saxpy3 (Source/GB_AxB_saxpy3.c:120).
- * A, B sparse/bitmap/full; M NULL | sparse | bitmap | full.
- * Returns GBA_NO_VALUE when a sparse mask is too costly and must be applied
- * later (Source/GB_AxB_saxpy3_slice_balanced.c:377-393). */
+ * A, B sparse (other formats are brought to sparse form by gba_mxm before it calls
+ * this); M NULL | sparse (sorted) | bitmap | full.  The mask is always applied inside
+ * the kernels (*mask_applied = true whenever M is given): the reference's policy of
+ * dropping a costly sparse mask and applying it afterwards
+ * (Source/GB_AxB_saxpy3_slice_balanced.c:377-393) is not reproduced, so GBA_NO_VALUE
+ * is never returned, and axb_method (GUSTAVSON / HASH hints) does not change the
+ * kernels -- every vector is routed by its own flop count.  vlen must be < 2^31. */
 gba_info gba_AxB_saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
                         const gba_matrix *A, const gba_matrix *B, const gba_semiring *semiring,
                         int32_t axb_method, int32_t do_sort, bool *mask_applied, gba_report *report);
@@ -306,6 +311,9 @@ gba_info gba_AxB_dot3(gba_matrix *C, const gba_matrix *M, bool Mask_struct,
                       const gba_matrix *A, const gba_matrix *B, const gba_semiring *semiring,
                       gba_report *report);
 
+/* The four methods below and gba_AxB_saxpy5 take A sparse (saxpy5: bitmap/full) and B bitmap/full
+ * (saxpy5: sparse) with at most 65535 vectors on the dense side; a larger problem is declined with
+ * GBA_NO_VALUE, and gba_mxm then computes it through the sparse path (same result). */
 /* C<#M> = A'*B, C bitmap: GB_AxB_dot2 (Source/GB_AxB_dot2.c:53). */
 gba_info gba_AxB_dot2(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
                       const gba_matrix *A, const gba_matrix *B, const gba_semiring *semiring,
