@@ -211,6 +211,7 @@ class _Lib:
             "gba_AxB_saxpy5": (i32, [M, M, M, S, R]),
             "gba_AxB_saxbit": (i32, [M, M, b, b, M, M, S, R]),
             "gba_cumsum": (i32, [vp, i64]),
+            "gba_cumsum_noalloc": (i32, [vp, i64]),
             "gba_matrix_wait": (i32, [M]),
             "gba_transpose": (i32, [M, M]),
             "gba_partition_by_flops": (i32, [P(i64), i32, M, M]),

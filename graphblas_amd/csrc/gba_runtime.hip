@@ -110,6 +110,55 @@ gba_info dev_cumsum_i64(int64_t *count, int64_t n, hipStream_t st) {
     return GBA_SUCCESS;
 }
 
+// ---- prefix sum without any allocation -------------------------------------------------------------
+// The tile sums of the three-step scan live in a device array that is part of the library's code object:
+// each GPU the library runs on holds its own copy at its own address until the process ends.  Host code
+// never passes the array's name to a kernel -- only the address hipGetSymbolAddress returned for the
+// device in use (taken in gba_init, with that device current).
+static constexpr int64_t NOALLOC_L1 = 65536;                     // level-1 tile sums (+ their total)
+static constexpr int64_t NOALLOC_L2 = 64, NOALLOC_L3 = 64;       // sums of the sums, twice
+static constexpr int64_t NOALLOC_SLOTS = NOALLOC_L1 + NOALLOC_L2 + NOALLOC_L3;
+static_assert((NOALLOC_L1 - 1 + SCAN_TILE) / SCAN_TILE + 1 <= NOALLOC_L2, "level 2 holds the tile sums of level 1");
+static __device__ __align__(256) int64_t scratch[NOALLOC_SLOTS];  // 525 312 bytes per GPU
+static constexpr int NOALLOC_MAX_DEVICES = 64;
+static int64_t *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {nullptr};   // device address of scratch[], per device
+
+static gba_info noalloc_bind_scratch(int device) {
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return GBA_SUCCESS;       // such a device gets no allocation-free scan
+    if (g_scratch_ptr[device]) return GBA_SUCCESS;
+    void *ptr = nullptr;
+    GBA_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));                 // the current device's copy
+    g_scratch_ptr[device] = reinterpret_cast<int64_t *>(ptr);
+    return GBA_SUCCESS;
+}
+
+// a[0..n] -> exclusive prefix sums in place; the tile sums of level k go to the k-th part of sc[]
+static gba_info noalloc_scan(int64_t *count, int64_t n, int64_t *sc, hipStream_t st) {
+    int64_t *lev[3] = {sc, sc + NOALLOC_L1, sc + NOALLOC_L1 + NOALLOC_L2};
+    const int64_t cap[3] = {NOALLOC_L1, NOALLOC_L2, NOALLOC_L3};
+    int64_t *a[3]; int64_t nn[3];
+    a[0] = count; nn[0] = n;
+    int depth = 0;
+    while (true) {
+        const int64_t ntiles = ceil_div(nn[depth] + 1, SCAN_TILE);
+        if (ntiles + 1 > cap[depth]) GBA_FAIL(GBA_PANIC, "cumsum: scratch level %d too small for %ld tiles", depth, (long)ntiles);
+        hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, st, a[depth], nn[depth], lev[depth]);
+        if (ntiles == 1) {
+            GBA_HIP(hipMemsetAsync(lev[depth], 0, sizeof(int64_t), st));    // the only tile starts at zero; the array keeps the last call's contents
+            break;
+        }
+        if (depth == 2) GBA_FAIL(GBA_PANIC, "cumsum: scratch levels exhausted");
+        a[depth + 1] = lev[depth]; nn[depth + 1] = ntiles;
+        depth++;
+    }
+    for (int d = depth; d >= 0; d--) {
+        const int64_t ntiles = ceil_div(nn[d] + 1, SCAN_TILE);
+        hipLaunchKernelGGL(scan_tiles, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, st, a[d], nn[d], lev[d]);
+    }
+    GBA_HIP(hipGetLastError());
+    return GBA_SUCCESS;
+}
+
 __global__ void fill_i64_kernel(int64_t *p, int64_t n, int64_t v) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -459,6 +508,7 @@ gba_info gba_init(int device) {
     GBA_HIP(hipEventCreate(&c.ev1));
     GBA_HIP(hipEventCreate(&c.tm0));
     GBA_HIP(hipEventCreate(&c.tm1));
+    GBA_OK(noalloc_bind_scratch(device));
     c.device = device;
     c.inited = true;
     size_t free_b = 0, total_b = 0;
@@ -552,6 +602,19 @@ gba_info gba_cumsum(int64_t *count_dev, int64_t n) {
     GBA_OK(require_init());
     if (!count_dev) GBA_FAIL(GBA_NULL_POINTER, "count is NULL");
     return dev_cumsum_i64(count_dev, n, ctx().stream);
+}
+
+gba_info gba_cumsum_noalloc(int64_t *count_dev, int64_t n) {
+    GBA_OK(require_init());
+    if (!count_dev) GBA_FAIL(GBA_NULL_POINTER, "count is NULL");
+    if (n < 0) GBA_FAIL(GBA_INVALID_VALUE, "cumsum: n < 0");
+    if (n > GBA_CUMSUM_NOALLOC_MAX)
+        GBA_FAIL(GBA_INVALID_VALUE, "gba_cumsum_noalloc: n = %ld exceeds the limit of %ld slots the built-in scratch array serves "
+                 "(use gba_cumsum)", (long)n, (long)GBA_CUMSUM_NOALLOC_MAX);
+    const int dev = ctx().device;
+    int64_t *sc = (dev >= 0 && dev < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[dev] : nullptr;
+    if (!sc) GBA_FAIL(GBA_PANIC, "gba_cumsum_noalloc: no scratch array bound for device %d", dev);
+    return noalloc_scan(count_dev, n, sc, ctx().stream);
 }
 
 }  // extern "C"

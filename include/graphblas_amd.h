@@ -342,6 +342,16 @@ gba_info gba_AxB_saxbit(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool
  * GB_cumsum (Source/GB_cumsum.c:23).  Device array. */
 gba_info gba_cumsum(int64_t *count_dev, int64_t n);
 
+/* The same prefix sum for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference (its
+ * GB_cumsum takes its workspace from the Werk stack).  Calls no hipMalloc / hipFree and does not
+ * synchronise: the kernels are queued on the library stream (gba_stream) and the tile sums of the
+ * scan live in a 525 312-byte device array inside the library, one copy per GPU, held until the
+ * process ends.  n <= GBA_CUMSUM_NOALLOC_MAX, larger n is rejected with GBA_INVALID_VALUE.  Every call
+ * on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+#define GBA_CUMSUM_NOALLOC_MAX ((int64_t)65535 * 2048 - 1)
+gba_info gba_cumsum_noalloc(int64_t *count_dev, int64_t n);
+
 /* Kill zombies and sort every vector: what GrB_wait(C, GrB_MATERIALIZE) does to
  * a jumbled saxpy3 result or a dot3 result with zombies (Source/GB_wait.c,
  * Source/GB_unjumble.c). */
