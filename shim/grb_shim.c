@@ -1,0 +1,479 @@
+/* Drop-in definitions of GrB_mxm, GrB_mxv and GrB_vxm (Include/GraphBLAS.h:4640-4671) in front of an
+ * unchanged SuiteSparse:GraphBLAS: a shared library that is linked or preloaded BEFORE libgraphblas.so.
+ *
+ *   1. the operands leave their opaque handles in O(1) through the public move interface,
+ *      GxB_Matrix_unpack_CSR/CSC/HyperCSR/HyperCSC/BitmapR/BitmapC/FullR/FullC and
+ *      GxB_Vector_unpack_CSC/Bitmap/Full (Include/GraphBLAS.h:9869-10158; O(1): 9298-9303);
+ *   2. gba_mxm / gba_mxv / gba_vxm run the multiply on the MI355X (include/graphblas_amd.h);
+ *   3. everything is packed back (GxB_Matrix_pack_*, GxB_Vector_pack_*, 9342-9760).
+ * A call the device path does not take (user-defined or complex types, iso-valued operands, an operator
+ * without a built-in code, GBA_NOT_IMPLEMENTED from the library) goes to the next definition of the same
+ * symbol, dlsym (RTLD_NEXT, ...): the CPU library, with its arguments untouched.
+ *
+ * Memory: the handles hold host arrays of the allocator given to GxB_init.  A, B and the mask are handed
+ * over as host views (mem = GBA_MEM_HOST; the library stages them over PCIe).  C travels to the device
+ * before the call and back after it, into arrays taken from that same allocator
+ * (GxB_Global_Option_get_FUNCTION (GxB_MALLOC_FUNCTION, ...)), which is what GxB_*_pack_* requires.
+ *
+ * Build:  gcc -O2 -fPIC -shared -I<reference>/Include -I<repo>/include shim/grb_shim.c \
+ *             -o libgrb_shim.so -L<repo>/graphblas_amd -lgraphblas_amd -ldl
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <string.h>
+#include <stdlib.h>
+#include "GraphBLAS.h"
+#include "graphblas_amd.h"
+
+/* the three definitions must have exactly the header's types */
+typedef GrB_Info (*shim_mxm_f) (GrB_Matrix, const GrB_Matrix, const GrB_BinaryOp, const GrB_Semiring,
+    const GrB_Matrix, const GrB_Matrix, const GrB_Descriptor) ;
+typedef GrB_Info (*shim_vxm_f) (GrB_Vector, const GrB_Vector, const GrB_BinaryOp, const GrB_Semiring,
+    const GrB_Vector, const GrB_Matrix, const GrB_Descriptor) ;
+typedef GrB_Info (*shim_mxv_f) (GrB_Vector, const GrB_Vector, const GrB_BinaryOp, const GrB_Semiring,
+    const GrB_Matrix, const GrB_Vector, const GrB_Descriptor) ;
+static const shim_mxm_f shim_check_mxm = GrB_mxm ;      /* a mismatch with the header is a compile error */
+static const shim_vxm_f shim_check_vxm = GrB_vxm ;
+static const shim_mxv_f shim_check_mxv = GrB_mxv ;
+
+#define SHIM_OK(call) do { if ((call) != GrB_SUCCESS) return (false) ; } while (0)
+
+/* ------------------------------------------------------------------ operators -- */
+
+static const struct { const char *name ; gba_opcode code ; } shim_ops [ ] = {
+    {"FIRST", GBA_FIRST}, {"SECOND", GBA_SECOND}, {"ANY", GBA_ANY}, {"PAIR", GBA_PAIR}, {"ONEB", GBA_PAIR},
+    {"MIN", GBA_MIN}, {"MAX", GBA_MAX}, {"PLUS", GBA_PLUS}, {"MINUS", GBA_MINUS}, {"RMINUS", GBA_RMINUS},
+    {"TIMES", GBA_TIMES}, {"DIV", GBA_DIV}, {"RDIV", GBA_RDIV}, {"ISEQ", GBA_ISEQ}, {"ISNE", GBA_ISNE},
+    {"ISGT", GBA_ISGT}, {"ISLT", GBA_ISLT}, {"ISGE", GBA_ISGE}, {"ISLE", GBA_ISLE}, {"LOR", GBA_LOR},
+    {"LAND", GBA_LAND}, {"LXOR", GBA_LXOR}, {"LXNOR", GBA_EQ}, {"BOR", GBA_BOR}, {"BAND", GBA_BAND},
+    {"BXOR", GBA_BXOR}, {"BXNOR", GBA_BXNOR}, {"EQ", GBA_EQ}, {"NE", GBA_NE}, {"GT", GBA_GT}, {"LT", GBA_LT},
+    {"GE", GBA_GE}, {"LE", GBA_LE}, {"FIRSTI", GBA_FIRSTI}, {"FIRSTI1", GBA_FIRSTI1}, {"FIRSTJ", GBA_FIRSTJ},
+    {"FIRSTJ1", GBA_FIRSTJ1}, {"SECONDI", GBA_SECONDI}, {"SECONDI1", GBA_SECONDI1}, {"SECONDJ", GBA_SECONDJ},
+    {"SECONDJ1", GBA_SECONDJ1} } ;
+
+/* GrB_Type_Code of a built-in real type -> gba_type (the codes agree for BOOL .. FP64) */
+static bool shim_type (gba_type *t, int32_t code)
+{
+    if (code < GrB_BOOL_CODE || code > GrB_FP64_CODE) return (false) ;      /* user-defined, complex */
+    (*t) = (gba_type) code ;
+    return (true) ;
+}
+
+/* "GrB_PLUS_FP64", "GxB_FIRSTJ_INT64", "GrB_LOR" -> opcode; the types come from the operator itself */
+static bool shim_binop (gba_opcode *code, gba_type *xtype, gba_type *ytype, gba_type *ztype, GrB_BinaryOp op)
+{
+    char name [GxB_MAX_NAME_LEN] ;
+    SHIM_OK (GrB_BinaryOp_get_String (op, name, GrB_NAME)) ;
+    const char *s = name ;
+    if (strncmp (s, "GrB_", 4) == 0 || strncmp (s, "GxB_", 4) == 0) s += 4 ; else return (false) ;
+    char base [GxB_MAX_NAME_LEN] ;
+    strncpy (base, s, sizeof (base) - 1) ; base [sizeof (base) - 1] = '\0' ;
+    char *us = strrchr (base, '_') ;
+    if (us != NULL)
+    {
+        static const char *types [ ] = {"BOOL", "INT8", "UINT8", "INT16", "UINT16", "INT32", "UINT32", "INT64",
+            "UINT64", "FP32", "FP64", "FC32", "FC64"} ;
+        for (size_t k = 0 ; k < sizeof (types) / sizeof (types [0]) ; k++)
+        {
+            if (strcmp (us + 1, types [k]) == 0) { (*us) = '\0' ; break ; }
+        }
+    }
+    bool found = false ;
+    for (size_t k = 0 ; k < sizeof (shim_ops) / sizeof (shim_ops [0]) ; k++)
+    {
+        if (strcmp (base, shim_ops [k].name) == 0) { (*code) = shim_ops [k].code ; found = true ; break ; }
+    }
+    if (!found) return (false) ;
+    int32_t xc, yc, zc ;
+    SHIM_OK (GrB_BinaryOp_get_INT32 (op, &zc, GrB_OUTP_TYPE_CODE)) ;
+    /* positional operators have no input types (GrB_NO_VALUE): their inputs are never read */
+    if (GrB_BinaryOp_get_INT32 (op, &xc, GrB_INP0_TYPE_CODE) != GrB_SUCCESS) xc = zc ;
+    if (GrB_BinaryOp_get_INT32 (op, &yc, GrB_INP1_TYPE_CODE) != GrB_SUCCESS) yc = zc ;
+    return (shim_type (xtype, xc) && shim_type (ytype, yc) && shim_type (ztype, zc)) ;
+}
+
+static bool shim_semiring (gba_semiring *s, GrB_Semiring semiring)
+{
+    GrB_Monoid monoid ; GrB_BinaryOp add, mult ;
+    SHIM_OK (GxB_Semiring_add (&monoid, semiring)) ;
+    SHIM_OK (GxB_Monoid_operator (&add, monoid)) ;
+    SHIM_OK (GxB_Semiring_multiply (&mult, semiring)) ;
+    gba_type ax, ay, az ;
+    if (!shim_binop (&(s->add), &ax, &ay, &az, add)) return (false) ;
+    if (!shim_binop (&(s->mult), &(s->xtype), &(s->ytype), &(s->ztype), mult)) return (false) ;
+    return (az == s->ztype) ;
+}
+
+static void shim_descriptor (gba_descriptor *d, GrB_Descriptor desc)
+{
+    memset (d, 0, sizeof (gba_descriptor)) ;
+    if (desc == NULL) return ;
+    int32_t v ;
+    if (GxB_Desc_get_INT32 (desc, GrB_OUTP, &v) == GrB_SUCCESS) d->out = v ;
+    if (GxB_Desc_get_INT32 (desc, GrB_MASK, &v) == GrB_SUCCESS) d->mask = v ;
+    if (GxB_Desc_get_INT32 (desc, GrB_INP0, &v) == GrB_SUCCESS) d->in0 = v ;
+    if (GxB_Desc_get_INT32 (desc, GrB_INP1, &v) == GrB_SUCCESS) d->in1 = v ;
+    if (GxB_Desc_get_INT32 (desc, GxB_AxB_METHOD, &v) == GrB_SUCCESS) d->axb = v ;
+    if (GxB_Desc_get_INT32 (desc, GxB_SORT, &v) == GrB_SUCCESS) d->do_sort = v ;
+}
+
+/* ------------------------------------------------------------------ operands -- */
+
+/* one operand out of its handle: the view handed to the device library, and what packing it back needs */
+typedef struct
+{
+    gba_matrix v ;
+    GrB_Matrix A ;              /* NULL for a vector */
+    GrB_Vector w ;
+    GrB_Index p_size, h_size, i_size, x_size, b_size ;
+    int64_t vecp [2] ;          /* the two "pointers" of a sparse vector (a vector is an n-by-1 CSC matrix) */
+    bool unpacked ;
+} shim_operand ;
+
+static bool shim_unpack_matrix (shim_operand *o, GrB_Matrix A)
+{
+    memset (o, 0, sizeof (shim_operand)) ;
+    o->A = A ;
+    gba_matrix *v = &(o->v) ;
+    GrB_Index nrows, ncols ; int32_t tcode, sparsity ; GxB_Format_Value fmt ; bool iso = false, jumbled = false ;
+    SHIM_OK (GrB_Matrix_nrows (&nrows, A)) ;
+    SHIM_OK (GrB_Matrix_ncols (&ncols, A)) ;
+    SHIM_OK (GrB_Matrix_get_INT32 (A, &tcode, GrB_EL_TYPE_CODE)) ;
+    if (!shim_type (&(v->type), tcode)) return (false) ;
+    SHIM_OK (GxB_Matrix_Option_get (A, GxB_SPARSITY_STATUS, &sparsity)) ;
+    SHIM_OK (GxB_Matrix_Option_get (A, GxB_FORMAT, &fmt)) ;
+    const bool by_row = (fmt == GxB_BY_ROW) ;
+    v->is_csc = !by_row ;
+    v->vlen = (int64_t) (by_row ? ncols : nrows) ;
+    v->vdim = (int64_t) (by_row ? nrows : ncols) ;
+    v->nvec = v->vdim ;
+    v->mem = GBA_MEM_HOST ;
+    v->sparsity = sparsity ;
+    GrB_Index nvals = 0, nvec = 0 ;
+    GrB_Info info ;
+    switch (sparsity)
+    {
+        case GxB_SPARSE :
+            info = by_row
+                ? GxB_Matrix_unpack_CSR (A, (GrB_Index **) &(v->p), (GrB_Index **) &(v->i), &(v->x), &(o->p_size), &(o->i_size), &(o->x_size), &iso, &jumbled, NULL)
+                : GxB_Matrix_unpack_CSC (A, (GrB_Index **) &(v->p), (GrB_Index **) &(v->i), &(v->x), &(o->p_size), &(o->i_size), &(o->x_size), &iso, &jumbled, NULL) ;
+            if (info != GrB_SUCCESS) return (false) ;
+            v->nvals = v->p [v->vdim] ;
+            break ;
+        case GxB_HYPERSPARSE :
+            info = by_row
+                ? GxB_Matrix_unpack_HyperCSR (A, (GrB_Index **) &(v->p), (GrB_Index **) &(v->h), (GrB_Index **) &(v->i), &(v->x), &(o->p_size), &(o->h_size), &(o->i_size), &(o->x_size), &iso, &nvec, &jumbled, NULL)
+                : GxB_Matrix_unpack_HyperCSC (A, (GrB_Index **) &(v->p), (GrB_Index **) &(v->h), (GrB_Index **) &(v->i), &(v->x), &(o->p_size), &(o->h_size), &(o->i_size), &(o->x_size), &iso, &nvec, &jumbled, NULL) ;
+            if (info != GrB_SUCCESS) return (false) ;
+            v->nvec = (int64_t) nvec ;
+            v->nvals = v->p [nvec] ;
+            break ;
+        case GxB_BITMAP :
+            info = by_row
+                ? GxB_Matrix_unpack_BitmapR (A, &(v->b), &(v->x), &(o->b_size), &(o->x_size), &iso, &nvals, NULL)
+                : GxB_Matrix_unpack_BitmapC (A, &(v->b), &(v->x), &(o->b_size), &(o->x_size), &iso, &nvals, NULL) ;
+            if (info != GrB_SUCCESS) return (false) ;
+            v->nvals = (int64_t) nvals ;
+            break ;
+        case GxB_FULL :
+            info = by_row
+                ? GxB_Matrix_unpack_FullR (A, &(v->x), &(o->x_size), &iso, NULL)
+                : GxB_Matrix_unpack_FullC (A, &(v->x), &(o->x_size), &iso, NULL) ;
+            if (info != GrB_SUCCESS) return (false) ;
+            v->nvals = v->vlen * v->vdim ;
+            break ;
+        default :
+            return (false) ;
+    }
+    v->iso = iso ; v->jumbled = jumbled ;
+    o->unpacked = true ;
+    return (true) ;
+}
+
+static bool shim_unpack_vector (shim_operand *o, GrB_Vector w)
+{
+    memset (o, 0, sizeof (shim_operand)) ;
+    o->w = w ;
+    gba_matrix *v = &(o->v) ;
+    GrB_Index n, nvals = 0 ; int32_t tcode, sparsity ; bool iso = false, jumbled = false ;
+    SHIM_OK (GrB_Vector_size (&n, w)) ;
+    SHIM_OK (GrB_Vector_get_INT32 (w, &tcode, GrB_EL_TYPE_CODE)) ;
+    if (!shim_type (&(v->type), tcode)) return (false) ;
+    SHIM_OK (GxB_Vector_Option_get (w, GxB_SPARSITY_STATUS, &sparsity)) ;
+    v->is_csc = true ; v->vlen = (int64_t) n ; v->vdim = 1 ; v->nvec = 1 ; v->mem = GBA_MEM_HOST ;
+    v->sparsity = sparsity ;
+    switch (sparsity)
+    {
+        case GxB_SPARSE :
+        case GxB_HYPERSPARSE :                       /* a hypersparse vector unpacks as a sparse one */
+            SHIM_OK (GxB_Vector_unpack_CSC (w, (GrB_Index **) &(v->i), &(v->x), &(o->i_size), &(o->x_size), &iso, &nvals, &jumbled, NULL)) ;
+            o->vecp [0] = 0 ; o->vecp [1] = (int64_t) nvals ;
+            v->p = o->vecp ; v->sparsity = GBA_SPARSE ;
+            break ;
+        case GxB_BITMAP :
+            SHIM_OK (GxB_Vector_unpack_Bitmap (w, &(v->b), &(v->x), &(o->b_size), &(o->x_size), &iso, &nvals, NULL)) ;
+            break ;
+        case GxB_FULL :
+            SHIM_OK (GxB_Vector_unpack_Full (w, &(v->x), &(o->x_size), &iso, NULL)) ;
+            nvals = n ;
+            break ;
+        default :
+            return (false) ;
+    }
+    v->nvals = (int64_t) nvals ;
+    v->iso = iso ; v->jumbled = jumbled ;
+    o->unpacked = true ;
+    return (true) ;
+}
+
+/* put the host arrays named by o->v back into the handle they came from (or, for C, the new ones) */
+static GrB_Info shim_pack (shim_operand *o)
+{
+    if (!o->unpacked) return (GrB_SUCCESS) ;
+    gba_matrix *v = &(o->v) ;
+    o->unpacked = false ;
+    if (o->A != NULL)
+    {
+        const bool by_row = !v->is_csc ;
+        switch (v->sparsity)
+        {
+            case GBA_SPARSE :
+                return (by_row
+                    ? GxB_Matrix_pack_CSR (o->A, (GrB_Index **) &(v->p), (GrB_Index **) &(v->i), &(v->x), o->p_size, o->i_size, o->x_size, v->iso, v->jumbled, NULL)
+                    : GxB_Matrix_pack_CSC (o->A, (GrB_Index **) &(v->p), (GrB_Index **) &(v->i), &(v->x), o->p_size, o->i_size, o->x_size, v->iso, v->jumbled, NULL)) ;
+            case GBA_HYPERSPARSE :
+                return (by_row
+                    ? GxB_Matrix_pack_HyperCSR (o->A, (GrB_Index **) &(v->p), (GrB_Index **) &(v->h), (GrB_Index **) &(v->i), &(v->x), o->p_size, o->h_size, o->i_size, o->x_size, v->iso, (GrB_Index) v->nvec, v->jumbled, NULL)
+                    : GxB_Matrix_pack_HyperCSC (o->A, (GrB_Index **) &(v->p), (GrB_Index **) &(v->h), (GrB_Index **) &(v->i), &(v->x), o->p_size, o->h_size, o->i_size, o->x_size, v->iso, (GrB_Index) v->nvec, v->jumbled, NULL)) ;
+            case GBA_BITMAP :
+                return (by_row
+                    ? GxB_Matrix_pack_BitmapR (o->A, &(v->b), &(v->x), o->b_size, o->x_size, v->iso, (GrB_Index) v->nvals, NULL)
+                    : GxB_Matrix_pack_BitmapC (o->A, &(v->b), &(v->x), o->b_size, o->x_size, v->iso, (GrB_Index) v->nvals, NULL)) ;
+            default :
+                return (by_row
+                    ? GxB_Matrix_pack_FullR (o->A, &(v->x), o->x_size, v->iso, NULL)
+                    : GxB_Matrix_pack_FullC (o->A, &(v->x), o->x_size, v->iso, NULL)) ;
+        }
+    }
+    switch (v->sparsity)
+    {
+        case GBA_SPARSE :
+            return (GxB_Vector_pack_CSC (o->w, (GrB_Index **) &(v->i), &(v->x), o->i_size, o->x_size, v->iso, (GrB_Index) v->nvals, v->jumbled, NULL)) ;
+        case GBA_BITMAP :
+            return (GxB_Vector_pack_Bitmap (o->w, &(v->b), &(v->x), o->b_size, o->x_size, v->iso, (GrB_Index) v->nvals, NULL)) ;
+        default :
+            return (GxB_Vector_pack_Full (o->w, &(v->x), o->x_size, v->iso, NULL)) ;
+    }
+}
+
+/* --------------------------------------------------------------- the output -- */
+
+static size_t shim_type_size (gba_type t)
+{
+    switch (t)
+    {
+        case GBA_BOOL : case GBA_INT8 : case GBA_UINT8 : return (1) ;
+        case GBA_INT16 : case GBA_UINT16 : return (2) ;
+        case GBA_INT32 : case GBA_UINT32 : case GBA_FP32 : return (4) ;
+        default : return (8) ;
+    }
+}
+
+/* bytes of each array of a view */
+static void shim_sizes (const gba_matrix *v, size_t *pb, size_t *hb, size_t *ib, size_t *xb, size_t *bb)
+{
+    const size_t dense = (size_t) v->vlen * (size_t) v->vdim, ts = shim_type_size (v->type) ;
+    const bool sparse = (v->sparsity == GBA_SPARSE || v->sparsity == GBA_HYPERSPARSE) ;
+    (*pb) = sparse ? (size_t) (v->nvec + 1) * 8 : 0 ;
+    (*hb) = (v->sparsity == GBA_HYPERSPARSE) ? (size_t) v->nvec * 8 : 0 ;
+    (*ib) = sparse ? (size_t) v->nvals * 8 : 0 ;
+    (*bb) = (v->sparsity == GBA_BITMAP) ? dense : 0 ;
+    (*xb) = v->iso ? ts : (sparse ? (size_t) v->nvals : dense) * ts ;
+}
+
+/* device copy of the host view of C (the library wants its in/out operand on the device) */
+static bool shim_upload (gba_matrix *dev, const gba_matrix *host)
+{
+    (*dev) = (*host) ;
+    dev->mem = GBA_MEM_DEVICE ;
+    dev->p = NULL ; dev->h = NULL ; dev->i = NULL ; dev->x = NULL ; dev->b = NULL ;
+    size_t pb, hb, ib, xb, bb ;
+    shim_sizes (host, &pb, &hb, &ib, &xb, &bb) ;
+    const void *src [5] = {host->p, host->h, host->i, host->x, host->b} ;
+    void **dst [5] = {(void **) &(dev->p), (void **) &(dev->h), (void **) &(dev->i), &(dev->x), (void **) &(dev->b)} ;
+    const size_t nb [5] = {pb, hb, ib, xb, bb} ;
+    for (int k = 0 ; k < 5 ; k++)
+    {
+        if (src [k] == NULL || (nb [k] == 0 && k != 3)) continue ;
+        (*dst [k]) = gba_malloc (nb [k] ? nb [k] : 1) ;
+        if ((*dst [k]) == NULL || (nb [k] && gba_memcpy_h2d ((*dst [k]), src [k], nb [k]) != GBA_SUCCESS))
+        {
+            gba_matrix_free_content (dev) ;
+            return (false) ;
+        }
+    }
+    return (true) ;
+}
+
+/* the result arrays come back to host memory of the library's allocator and replace those of C */
+static bool shim_download (shim_operand *c, gba_matrix *dev)
+{
+    void *(*lib_malloc) (size_t) = NULL ; void (*lib_free) (void *) = NULL ;
+    if (GxB_Global_Option_get_FUNCTION (GxB_MALLOC_FUNCTION, (void **) &lib_malloc) != GrB_SUCCESS || lib_malloc == NULL) return (false) ;
+    if (GxB_Global_Option_get_FUNCTION (GxB_FREE_FUNCTION, (void **) &lib_free) != GrB_SUCCESS || lib_free == NULL) return (false) ;
+    if (dev->nzombies > 0 && gba_matrix_wait (dev) != GBA_SUCCESS) return (false) ;     /* a packed matrix has no zombies */
+    if (dev->sparsity == GBA_HYPERSPARSE) return (false) ;
+    gba_matrix h = (*dev) ;
+    h.mem = GBA_MEM_HOST ; h.p = NULL ; h.h = NULL ; h.i = NULL ; h.x = NULL ; h.b = NULL ;
+    size_t pb, hb, ib, xb, bb ;
+    shim_sizes (dev, &pb, &hb, &ib, &xb, &bb) ;
+    const void *src [5] = {dev->p, dev->h, dev->i, dev->x, dev->b} ;
+    void **dst [5] = {(void **) &(h.p), (void **) &(h.h), (void **) &(h.i), &(h.x), (void **) &(h.b)} ;
+    const size_t need [5] = {pb, hb, ib, xb, bb} ;                          /* bytes to copy */
+    size_t nb [5] ;                                                         /* bytes to allocate: pack wants non-NULL arrays */
+    const bool sparse = (dev->sparsity == GBA_SPARSE) ;
+    const bool wanted [5] = {sparse, false, sparse, true, dev->sparsity == GBA_BITMAP} ;
+    bool ok = true ;
+    for (int k = 0 ; k < 5 ; k++)
+    {
+        nb [k] = 0 ;
+        if (!wanted [k] || !ok) continue ;
+        nb [k] = need [k] ? need [k] : 8 ;
+        (*dst [k]) = lib_malloc (nb [k]) ;
+        ok = ((*dst [k]) != NULL) && (need [k] == 0 || (src [k] != NULL && gba_memcpy_d2h ((*dst [k]), src [k], need [k]) == GBA_SUCCESS)) ;
+    }
+    if (!ok)
+    {
+        lib_free (h.p) ; lib_free (h.i) ; lib_free (h.x) ; lib_free (h.b) ;
+        return (false) ;
+    }
+    /* the old host arrays of C are not needed any more */
+    gba_matrix *old = &(c->v) ;
+    if (old->p != c->vecp) lib_free (old->p) ;
+    lib_free (old->h) ; lib_free (old->i) ; lib_free (old->x) ; lib_free (old->b) ;
+    const bool is_vector = (c->w != NULL) ;
+    c->v = h ;
+    c->p_size = nb [0] ; c->h_size = 0 ; c->i_size = nb [2] ; c->x_size = nb [3] ; c->b_size = nb [4] ;
+    if (is_vector && h.sparsity == GBA_SPARSE)
+    {
+        int64_t nv = h.p [1] ;                                              /* Vector_pack_CSC takes nvals, not p */
+        lib_free (h.p) ; c->v.p = c->vecp ; c->v.nvals = nv ;
+    }
+    return (true) ;
+}
+
+/* ------------------------------------------------------------------ the call -- */
+
+typedef struct
+{
+    shim_operand c, m, a, b ;
+    bool has_mask ;
+} shim_call ;
+
+static void shim_repack_inputs (shim_call *k)
+{
+    shim_pack (&(k->a)) ; shim_pack (&(k->b)) ;
+    if (k->has_mask) shim_pack (&(k->m)) ;
+}
+
+/* true: handled on the device, *result is the GrB_Info to return.  false: nothing was changed, the caller
+   passes the call on to the CPU library. */
+static bool shim_run (GrB_Info *result, int which, shim_call *k, const GrB_BinaryOp accum,
+    const GrB_Semiring semiring, const GrB_Descriptor desc)
+{
+    gba_semiring s ; gba_binop acc ; gba_descriptor d ;
+    if (semiring == NULL || !shim_semiring (&s, semiring)) return (false) ;
+    acc.op = GBA_NOP ; acc.type = s.ztype ;
+    if (accum != NULL)
+    {
+        gba_type ax, ay ;
+        if (!shim_binop (&(acc.op), &ax, &ay, &(acc.type), accum)) return (false) ;
+    }
+    shim_descriptor (&d, desc) ;
+    static bool inited = false ;
+    if (!inited)
+    {
+        const char *dev = getenv ("GBA_DEVICE") ;
+        if (gba_init (dev ? atoi (dev) : 0) != GBA_SUCCESS) return (false) ;
+        inited = true ;
+    }
+    gba_matrix cdev ;
+    if (k->c.v.iso || !shim_upload (&cdev, &(k->c.v))) return (false) ;
+    const gba_matrix *m = k->has_mask ? &(k->m.v) : NULL ;
+    gba_info info ;
+    if (which == 0) info = gba_mxm (&cdev, m, accum ? &acc : NULL, &s, &(k->a.v), &(k->b.v), &d, NULL) ;
+    else if (which == 1) info = gba_vxm (&cdev, m, accum ? &acc : NULL, &s, &(k->a.v), &(k->b.v), &d, NULL) ;
+    else info = gba_mxv (&cdev, m, accum ? &acc : NULL, &s, &(k->a.v), &(k->b.v), &d, NULL) ;
+    bool taken = (info != GBA_NOT_IMPLEMENTED && info != GBA_NO_VALUE) ;
+    if (taken && info == GBA_SUCCESS) taken = shim_download (&(k->c), &cdev) ;
+    gba_matrix_free_content (&cdev) ;
+    if (taken) (*result) = (GrB_Info) info ;          /* the codes are the reference's (GrB_Info) */
+    return (taken) ;
+}
+
+GrB_Info GrB_mxm (GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+    const GrB_Matrix A, const GrB_Matrix B, const GrB_Descriptor desc)
+{
+    static shim_mxm_f next = NULL ;
+    if (next == NULL) next = (shim_mxm_f) dlsym (RTLD_NEXT, "GrB_mxm") ;
+    (void) shim_check_mxm ;
+    /* aliased handles cannot be moved out twice: those calls stay on the CPU */
+    bool ok = (C != NULL && A != NULL && B != NULL && C != A && C != B && A != B && C != Mask && Mask != A && Mask != B) ;
+    shim_call k ; memset (&k, 0, sizeof (k)) ;
+    GrB_Info result = GrB_SUCCESS ;
+    if (ok)
+    {
+        k.has_mask = (Mask != NULL) ;
+        ok = shim_unpack_matrix (&(k.a), A) && shim_unpack_matrix (&(k.b), B)
+            && (!k.has_mask || shim_unpack_matrix (&(k.m), Mask)) && shim_unpack_matrix (&(k.c), C) ;
+        if (ok) ok = shim_run (&result, 0, &k, accum, semiring, desc) ;
+        shim_repack_inputs (&k) ;
+        shim_pack (&(k.c)) ;
+    }
+    if (ok) return (result) ;
+    return (next ? next (C, Mask, accum, semiring, A, B, desc) : GrB_PANIC) ;
+}
+
+GrB_Info GrB_vxm (GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+    const GrB_Vector u, const GrB_Matrix A, const GrB_Descriptor desc)
+{
+    static shim_vxm_f next = NULL ;
+    if (next == NULL) next = (shim_vxm_f) dlsym (RTLD_NEXT, "GrB_vxm") ;
+    (void) shim_check_vxm ;
+    bool ok = (w != NULL && u != NULL && A != NULL && w != u && w != mask && mask != u) ;
+    shim_call k ; memset (&k, 0, sizeof (k)) ;
+    GrB_Info result = GrB_SUCCESS ;
+    if (ok)
+    {
+        k.has_mask = (mask != NULL) ;
+        ok = shim_unpack_vector (&(k.a), u) && shim_unpack_matrix (&(k.b), A)
+            && (!k.has_mask || shim_unpack_vector (&(k.m), mask)) && shim_unpack_vector (&(k.c), w) ;
+        if (ok) ok = shim_run (&result, 1, &k, accum, semiring, desc) ;
+        shim_repack_inputs (&k) ;
+        shim_pack (&(k.c)) ;
+    }
+    if (ok) return (result) ;
+    return (next ? next (w, mask, accum, semiring, u, A, desc) : GrB_PANIC) ;
+}
+
+GrB_Info GrB_mxv (GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+    const GrB_Matrix A, const GrB_Vector u, const GrB_Descriptor desc)
+{
+    static shim_mxv_f next = NULL ;
+    if (next == NULL) next = (shim_mxv_f) dlsym (RTLD_NEXT, "GrB_mxv") ;
+    (void) shim_check_mxv ;
+    bool ok = (w != NULL && u != NULL && A != NULL && w != u && w != mask && mask != u) ;
+    shim_call k ; memset (&k, 0, sizeof (k)) ;
+    GrB_Info result = GrB_SUCCESS ;
+    if (ok)
+    {
+        k.has_mask = (mask != NULL) ;
+        ok = shim_unpack_matrix (&(k.a), A) && shim_unpack_vector (&(k.b), u)
+            && (!k.has_mask || shim_unpack_vector (&(k.m), mask)) && shim_unpack_vector (&(k.c), w) ;
+        if (ok) ok = shim_run (&result, 2, &k, accum, semiring, desc) ;
+        shim_repack_inputs (&k) ;
+        shim_pack (&(k.c)) ;
+    }
+    if (ok) return (result) ;
+    return (next ? next (w, mask, accum, semiring, A, u, desc) : GrB_PANIC) ;
+}
