@@ -37,14 +37,33 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`--gpus N` with N > 1 from a plain `python bench.py`: start N ranks (one process per GPU, RCCL) and pass
+    their exit code on.  Nothing has touched the GPU yet: the ranks are children, not a replacement of this
+    process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     if os.environ.get("GBA_BENCH_WATCHDOG"):                # a hang prints every thread's stack and ends the process
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["GBA_BENCH_WATCHDOG"]), exit=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     import torch
     dist = None
     if world > 1:
@@ -72,16 +91,27 @@ def main():
     total_madds = int(prefix[-1])
     gen_s = time.time() - t0
 
-    # 1-D partition of rows over ranks, balanced by flops (the same count saxpy3 bins by)
-    part = split_by_flops(prefix, 0, n, world)
-    my_lo, my_hi = part[rank], part[rank + 1]
-    my_chunks = chunks_by_flops(prefix, my_lo, my_hi, args.chunk_flops)
-
     # device copies.  Right-hand operand: full A on every rank, held in torch tensors so that RCCL can fill them.
     dev = torch.device("cuda", local_rank)
     Bp = torch.from_numpy(A.p).to(dev)
     Bi = torch.empty(nnzA, dtype=torch.int64, device=dev)
     Bx = torch.empty(nnzA, dtype=torch.float64, device=dev)
+
+    # 1-D partition of rows over ranks, balanced by flops: the library's own split (the per-vector count saxpy3
+    # bins by, gba_partition_by_flops), taken once on the pattern before the timed region
+    if world > 1:
+        Bi.copy_(torch.from_numpy(A.i))
+        m0 = gba_matrix()
+        m0.vlen, m0.vdim, m0.nvec, m0.nvals = n, n, n, nnzA
+        m0.p, m0.i, m0.x = Bp.data_ptr(), Bi.data_ptr(), Bx.data_ptr()
+        m0.type, m0.sparsity, m0.mem, m0.is_csc = Type.FP64, g.Sparsity.SPARSE, 0, False
+        whole = DeviceMatrix(m0, owns=False)
+        part = g.partition_by_flops(world, whole, whole)
+        Bi.fill_(-1)                                      # the timed steps gather it again from the row blocks
+    else:
+        part = split_by_flops(prefix, 0, n, world)
+    my_lo, my_hi = part[rank], part[rank + 1]
+    my_chunks = chunks_by_flops(prefix, my_lo, my_hi, args.chunk_flops)
     e_lo, e_hi = int(A.p[my_lo]), int(A.p[my_hi])
     my_i = torch.from_numpy(A.i[e_lo:e_hi]).to(dev)
     my_x = torch.from_numpy(A.x[e_lo:e_hi]).to(dev)

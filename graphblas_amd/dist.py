@@ -6,6 +6,10 @@ Source/GB_AxB_saxpy3_flopcount.c:81; RMAT rows follow a power law, so equal row 
 not balance).  The only exchange is the all-gather of the right-hand operand when it is itself
 distributed by rows (C = A*A): every rank contributes the entries of its row block.
 
+The other products of the path shard the same way, by row blocks of the output: y(I) = A(I,:) x needs the
+all-gather of x (VectorBlockExchange), a traversal step w(I)<!visited> = A(I,:) q the exchange of the
+frontier (FrontierExchange: index lists while it is small, a dense reduce once it is large).
+
 The helpers work on any torch.distributed backend ("nccl" is RCCL on ROCm; "gloo" on CPU).
 """
 import numpy as np
@@ -42,12 +46,27 @@ def chunks_by_flops(prefix, lo, hi, max_flops):
     return out
 
 
+def _all_gather_padded(dist, torch, send, pad, world):
+    """One collective: every rank contributes `pad` elements, the result is the flat [world * pad] buffer.
+    gloo moves host memory, so device tensors are staged through the host there (CPU rehearsals of the
+    path only; RCCL takes the device tensors as they are)."""
+    flat = torch.empty(world * pad, dtype=send.dtype, device=send.device)
+    if dist.get_backend() == "gloo" and send.is_cuda:
+        host = torch.empty(world * pad, dtype=send.dtype)
+        dist.all_gather_into_tensor(host, send.cpu())
+        flat.copy_(host)
+    else:
+        dist.all_gather_into_tensor(flat, send)
+    return flat
+
+
 class RowBlockExchange:
     """All-gather of the (i, x) arrays of a matrix distributed by row blocks.
 
     part[r]..part[r+1] are the rows of rank r and Ap the (replicated) row pointers, so entry
-    ranges are known everywhere and only indices and values travel.  Blocks are padded to the
-    longest one because all_gather wants equal shapes."""
+    ranges are known everywhere and only indices and values travel: one all_gather_into_tensor per
+    array on a flat buffer (blocks padded to the longest one, the collective wants equal shares),
+    then one device copy per block into its place."""
 
     def __init__(self, dist, torch, Ap, part, rank, device, idx_dtype, val_dtype):
         self.dist, self.torch = dist, torch
@@ -55,10 +74,8 @@ class RowBlockExchange:
         self.rank = rank
         self.offs = [int(Ap[part[r]]) for r in range(self.world)]
         self.counts = [int(Ap[part[r + 1]] - Ap[part[r]]) for r in range(self.world)]
-        self.pad = max(self.counts) if self.world > 1 else 0
+        self.pad = max(max(self.counts), 1) if self.world > 1 else 0
         if self.world > 1:
-            self.gi = [torch.empty(self.pad, dtype=idx_dtype, device=device) for _ in range(self.world)]
-            self.gx = [torch.empty(self.pad, dtype=val_dtype, device=device) for _ in range(self.world)]
             self.si = torch.zeros(self.pad, dtype=idx_dtype, device=device)
             self.sx = torch.zeros(self.pad, dtype=val_dtype, device=device)
 
@@ -68,19 +85,86 @@ class RowBlockExchange:
             out_i.copy_(my_i); out_x.copy_(my_x)
             return
         c = self.counts[self.rank]
-        self.si[:c] = my_i; self.sx[:c] = my_x
-        if self.dist.get_backend() == "gloo" and self.si.is_cuda:
-            # gloo moves host memory: device tensors are staged through the host (CPU rehearsals of the path only;
-            # RCCL takes the device tensors as they are)
-            for send, recv in ((self.si, self.gi), (self.sx, self.gx)):
-                host = [self.torch.empty(self.pad, dtype=send.dtype) for _ in range(self.world)]
-                self.dist.all_gather(host, send.cpu())
-                for r in range(self.world):
-                    recv[r].copy_(host[r])
-        else:
-            self.dist.all_gather(self.gi, self.si)
-            self.dist.all_gather(self.gx, self.sx)
+        self.si[:c].copy_(my_i); self.sx[:c].copy_(my_x)
+        for send, out in ((self.si, out_i), (self.sx, out_x)):
+            flat = _all_gather_padded(self.dist, self.torch, send, self.pad, self.world)
+            for r in range(self.world):
+                o, n = self.offs[r], self.counts[r]
+                out[o: o + n].copy_(flat[r * self.pad: r * self.pad + n])
+
+
+class VectorBlockExchange:
+    """A dense vector distributed by the same row blocks: y(I) is computed by the rank that owns rows I
+    (y(I) = A(I,:) x needs all of x), and the blocks are all-gathered into the full vector that the next
+    product reads -- the exchange of a PageRank-shaped iteration x <- A x (GrB_mxv, Source/GrB_mxv.c:57-66)."""
+
+    def __init__(self, dist, torch, part, rank, device, dtype):
+        self.dist, self.torch = dist, torch
+        self.world, self.rank = len(part) - 1, rank
+        self.part = [int(v) for v in part]
+        self.counts = [self.part[r + 1] - self.part[r] for r in range(self.world)]
+        self.pad = max(max(self.counts), 1)
+        self.send = torch.zeros(self.pad, dtype=dtype, device=device) if self.world > 1 else None
+
+    def gather(self, my_block, out):
+        """my_block: this rank's entries y(I); out: the full-length vector to fill."""
+        if self.world == 1:
+            out.copy_(my_block)
+            return
+        self.send[: self.counts[self.rank]].copy_(my_block)
+        flat = _all_gather_padded(self.dist, self.torch, self.send, self.pad, self.world)
         for r in range(self.world):
-            o, n = self.offs[r], self.counts[r]
-            out_i[o: o + n] = self.gi[r][:n]
-            out_x[o: o + n] = self.gx[r][:n]
+            out[self.part[r]: self.part[r + 1]].copy_(flat[r * self.pad: r * self.pad + self.counts[r]])
+
+
+class FrontierExchange:
+    """The frontier of a level-synchronous traversal (BFS parents with ANY_SECONDI, SSSP distances with
+    MIN_PLUS), distributed by row blocks of the OUTPUT: rank r computes w(I)<!visited(I)> = A(I,:) q for its
+    rows I -- GrB_mxv with the full frontier q as the second operand; on a symmetric graph the same step as
+    the push form q'A of GrB_vxm (Source/GrB_vxm.c:63-72) -- and the pieces are exchanged so that every rank
+    holds the whole next frontier.
+
+    sparse(): a small frontier travels as (index, value) lists: the counts first, then ONE padded
+    all-gather per array.  dense_min() / dense_or(): a large frontier travels as a dense n-vector reduced
+    with MIN (distances) or as a bitmap reduced with MAX (presence).  No reduction of w itself is needed:
+    the row blocks are disjoint."""
+
+    def __init__(self, dist, torch, rank, world, device):
+        self.dist, self.torch, self.rank, self.world, self.device = dist, torch, rank, world, device
+
+    def sparse(self, my_idx, my_val):
+        """my_idx: global indices of the entries this rank found (ascending), my_val their values.
+        Returns the concatenation over ranks, in rank order (= ascending index order for row blocks)."""
+        torch = self.torch
+        if self.world == 1:
+            return my_idx, my_val
+        cnt = torch.tensor([my_idx.numel()], dtype=torch.int64, device=self.device)
+        counts = _all_gather_padded(self.dist, torch, cnt, 1, self.world).cpu().tolist()
+        pad = max(max(counts), 1)
+        out = []
+        for mine in (my_idx, my_val):
+            send = torch.zeros(pad, dtype=mine.dtype, device=self.device)
+            send[: mine.numel()].copy_(mine)
+            flat = _all_gather_padded(self.dist, torch, send, pad, self.world)
+            out.append(torch.cat([flat[r * pad: r * pad + counts[r]] for r in range(self.world)]))
+        return out[0], out[1]
+
+    def dense_min(self, d):
+        """d: a full-length vector that holds this rank's block and the monoid identity (+inf) elsewhere."""
+        if self.world > 1:
+            self._all_reduce(d, self.dist.ReduceOp.MIN)
+        return d
+
+    def dense_or(self, b):
+        """b: a full-length int8 bitmap that is zero outside this rank's block."""
+        if self.world > 1:
+            self._all_reduce(b, self.dist.ReduceOp.MAX)
+        return b
+
+    def _all_reduce(self, t, op):
+        if self.dist.get_backend() == "gloo" and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=op)

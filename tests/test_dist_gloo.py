@@ -80,3 +80,105 @@ def test_two_ranks_over_gloo_reproduce_the_product(tmp_path):
     p = np.concatenate([blocks[0]["p"], blocks[1]["p"][1:] + blocks[0]["p"][-1]])
     i = np.concatenate([b["i"] for b in blocks]); x = np.concatenate([b["x"] for b in blocks])
     assert np.array_equal(p, want.p) and np.array_equal(i, want.i) and np.array_equal(x, want.x)
+
+
+def _bfs_levels(S, src, rows=None, exchange=None, torch=None):
+    """Level-synchronous BFS on the symmetric pattern S (scipy CSR): per level, w(I)<!visited(I)> = S(I,:) q with
+    ANY_SECONDI -- any frontier neighbour is a valid parent; the smallest one is taken so that runs compare
+    exactly -- for the rows I = rows this caller owns.  Returns the list of (indices, parents) per level."""
+    n = S.shape[0]
+    lo, hi = (0, n) if rows is None else rows
+    visited = np.zeros(n, bool); visited[src] = True
+    q_idx = np.array([src], np.int64)
+    levels = []
+    while len(q_idx):
+        inq = np.zeros(n, bool); inq[q_idx] = True
+        found, parents = [], []
+        for i in range(lo, hi):
+            if visited[i]:
+                continue
+            nb = S.indices[S.indptr[i]:S.indptr[i + 1]]
+            nb = nb[inq[nb]]
+            if len(nb):
+                found.append(i); parents.append(nb.min())
+        found, parents = np.array(found, np.int64), np.array(parents, np.int64)
+        if exchange is not None:
+            gi, gp = exchange.sparse(torch.from_numpy(found), torch.from_numpy(parents))
+            found, parents = gi.numpy(), gp.numpy()
+        levels.append((found, parents))
+        visited[found] = True
+        q_idx = found
+    return levels
+
+
+def _worker_vectors(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import scipy.sparse as sp
+    import torch
+    import torch.distributed as dist
+    from graphblas_amd import gen, Type
+    from graphblas_amd.dist import VectorBlockExchange, FrontierExchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # --- x <- A x, three times, y distributed by flop-balanced row blocks, x all-gathered
+    A = gen.rmat(9, 8, seed=42, type=Type.FP32)
+    n = A.nrows
+    S = sp.csr_matrix((A.x, A.i, A.p), shape=(n, n))
+    prefix = np.concatenate([[0], np.cumsum(np.diff(A.p))])          # SpMV work = entries per row
+    part = split_by_flops(prefix, 0, n, world)
+    lo, hi = part[rank], part[rank + 1]
+    x = torch.from_numpy(np.linspace(0.5, 1.5, n).astype(np.float32))
+    xchg = VectorBlockExchange(dist, torch, part, rank, torch.device("cpu"), torch.float32)
+    for _ in range(3):
+        mine = torch.from_numpy((S[lo:hi] @ x.numpy()).astype(np.float32))
+        full = torch.empty(n, dtype=torch.float32)
+        xchg.gather(mine, full)
+        x = full / full.abs().max()
+    # --- BFS from the heaviest vertex, the new frontier exchanged as index lists; SSSP-style dense MIN reduce
+    G = gen.rmat(9, 8, seed=7, symmetric=True, drop_diagonal=True, values="ones")
+    Sg = sp.csr_matrix((G.x, G.i, G.p), shape=(G.nrows, G.nrows))
+    deg = np.diff(G.p)
+    gpart = split_by_flops(np.concatenate([[0], np.cumsum(deg)]), 0, G.nrows, world)
+    fx = FrontierExchange(dist, torch, rank, world, torch.device("cpu"))
+    levels = _bfs_levels(Sg, int(np.argmax(deg)), rows=(gpart[rank], gpart[rank + 1]), exchange=fx, torch=torch)
+    d = torch.full((G.nrows,), float("inf"), dtype=torch.float64)
+    d[gpart[rank]:gpart[rank + 1]] = torch.arange(gpart[rank], gpart[rank + 1], dtype=torch.float64) % 7
+    fx.dense_min(d)
+    b = torch.zeros(G.nrows, dtype=torch.int8); b[gpart[rank]:gpart[rank + 1]:3] = 1
+    fx.dense_or(b)
+    np.savez(os.path.join(outdir, f"v{rank}.npz"), x=x.numpy(), d=d.numpy(), b=b.numpy(),
+             **{f"i{k}": lv[0] for k, lv in enumerate(levels)}, **{f"p{k}": lv[1] for k, lv in enumerate(levels)},
+             nlevels=len(levels), gpart=np.array(gpart))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_spmv_iterations_and_bfs_levels(tmp_path):
+    """x <- A x with the all-gather of x, and BFS with the frontier exchange, on two ranks over gloo: every rank ends
+    with exactly the single-process result."""
+    import scipy.sparse as sp
+    import torch.multiprocessing as mp
+    from graphblas_amd import gen, Type
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_vectors, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    A = gen.rmat(9, 8, seed=42, type=Type.FP32)
+    S = sp.csr_matrix((A.x, A.i, A.p), shape=(A.nrows, A.nrows))
+    x = np.linspace(0.5, 1.5, A.nrows).astype(np.float32)
+    for _ in range(3):
+        y = (S @ x).astype(np.float32)
+        x = y / np.abs(y).max()
+    G = gen.rmat(9, 8, seed=7, symmetric=True, drop_diagonal=True, values="ones")
+    Sg = sp.csr_matrix((G.x, G.i, G.p), shape=(G.nrows, G.nrows))
+    want_levels = _bfs_levels(Sg, int(np.argmax(np.diff(G.p))))
+    assert len(want_levels) > 3
+    for r in range(world):
+        got = np.load(tmp_path / f"v{r}.npz")
+        assert np.array_equal(got["x"], x), f"rank {r}: x after three products differs"
+        assert int(got["nlevels"]) == len(want_levels)
+        for k, (wi, wp) in enumerate(want_levels):
+            assert np.array_equal(got[f"i{k}"], wi) and np.array_equal(got[f"p{k}"], wp), (r, k)
+        gp = got["gpart"]
+        assert np.array_equal(got["d"], np.arange(G.nrows) % 7)
+        wb = np.zeros(G.nrows, np.int8)
+        for q in range(world):
+            wb[gp[q]:gp[q + 1]:3] = 1
+        assert np.array_equal(got["b"], wb)

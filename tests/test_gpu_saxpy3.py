@@ -188,3 +188,22 @@ def test_checksum_property_large(gba):
     vec = np.repeat(np.arange(got.vdim), np.diff(got.p))
     key = vec * got.vlen + got.i
     assert len(np.unique(key)) == len(key)
+
+
+def test_partition_by_flops_matches_the_host_split(gba):
+    """gba_partition_by_flops (the GB_pslice analogue the multi-GPU bench shards rows by) against the numpy
+    split of the same per-vector flop count: contiguous, covering, and balanced to within one vector."""
+    from graphblas_amd.dist import row_flops, split_by_flops
+    A = gen.rmat(12, 16, seed=42)                                  # CSR
+    dA = A.to_device()
+    rf = row_flops(A.p, A.i) + np.diff(A.p)                        # the reference's count includes nnz B(:,j) itself
+    prefix = np.concatenate([[0], np.cumsum(rf)]).astype(np.int64)
+    for nparts in (1, 2, 3, 8):
+        part = gba.partition_by_flops(nparts, dA, dA)
+        want = split_by_flops(prefix, 0, A.nrows, nparts)
+        assert part[0] == 0 and part[-1] == A.nrows and len(part) == nparts + 1
+        assert all(a <= b for a, b in zip(part, part[1:]))
+        assert all(abs(a - b) <= 1 for a, b in zip(part, want)), (part, want)
+        loads = np.diff(prefix[np.array(part)])
+        assert loads.max() <= prefix[-1] / nparts + rf.max()
+    dA.free()
