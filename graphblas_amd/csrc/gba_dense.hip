@@ -173,11 +173,29 @@ __device__ inline void dot_commit(const S &sr, const MaskViewD &M, int64_t i, in
     if (MODE == 1) Cb[pC] = 1;
 }
 
+// tile_row[t] = the row that holds entry t * tile of A (the largest r with Ap[r] <= Ap[0] + t * tile):
+// one pass over the row pointers, each row naming the tiles that start inside it.  A tile then learns its
+// first row from one load instead of a search of Ap with several dependent probes.
+__global__ void __launch_bounds__(256)
+dot_tile_rows_kernel(int64_t nvec, const int64_t *__restrict__ Ap, int64_t tile, int64_t *__restrict__ tile_row) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t p0 = Ap[0];
+    for (; r < nvec; r += stride) {
+        const int64_t a0 = Ap[r] - p0, a1 = Ap[r + 1] - p0;
+        if (a1 <= a0) continue;
+        for (int64_t t = (a0 + tile - 1) / tile; t * tile < a1; t++) tile_row[t] = r;
+    }
+}
+
+static constexpr int DOT_SEG_SERIAL = 32;       // row segments longer than this are reduced by a whole wave
+
 template <class S, int MODE>
 __global__ void __launch_bounds__(DOT_TILE_THREADS)
 dot_tile_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
                 const void *__restrict__ Ax_, bool A_iso, DenseView B, MaskViewD M,
-                typename S::z_t *__restrict__ Cx, int8_t *__restrict__ Cb, int64_t cvlen) {
+                typename S::z_t *__restrict__ Cx, int8_t *__restrict__ Cb, int64_t cvlen,
+                const int64_t *__restrict__ tile_row) {
     using X = typename S::x_t; using Z = typename S::z_t;
     __shared__ Z prod[DOT_TILE];
     __shared__ uint8_t have[DOT_TILE];
@@ -191,60 +209,84 @@ dot_tile_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64
     const int64_t start = Ap[0] + (int64_t)blockIdx.x * DOT_TILE;
     if (start >= pN) return;                                  // uniform
     const int64_t end = (start + DOT_TILE < pN) ? start + DOT_TILE : pN;
-    // r0 = row holding the first entry of the tile = largest r with Ap[r] <= start.  The 256 threads
-    // probe 256 evenly spaced rows per round (three rounds for 2^24 rows) instead of bisecting.
-    int64_t r0;
-    {
-        int64_t lo = 0, hi = nvecA - 1;                       // candidates, inclusive
-        while (lo < hi) {
-            const int64_t span = hi - lo;                     // probes lo+1 .. hi, non-decreasing in tid
-            const int64_t probe = lo + 1 + (span - 1) * tid / (DOT_TILE_THREADS - 1);
-            const int c = __syncthreads_count(Ap[probe] <= start);     // monotone: the first c threads
-            const int64_t below = (c > 0) ? lo + 1 + (span - 1) * (c - 1) / (DOT_TILE_THREADS - 1) : lo;
-            const int64_t above = (c < DOT_TILE_THREADS) ? lo + 1 + (span - 1) * c / (DOT_TILE_THREADS - 1) : hi + 1;
-            lo = below; hi = above - 1;
-        }
-        r0 = lo;
-    }
+    const int64_t r0 = tile_row[blockIdx.x];                  // row holding the first entry of the tile
+    __shared__ int longq[DOT_TILE / DOT_SEG_SERIAL + 2];
+    __shared__ int nlongq;
+    if (tid == 0) nlongq = 0;
     const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
     const int64_t boff = j * B.vlen;
+    const bool plain = !B.b;                                  // every entry of B present: have[] is not used
+    // the row pointers the reduction needs, asked for before the entries so that they arrive with them
+    const int64_t next0 = Ap[r0 + 1];
+    const int64_t rmine = r0 + tid;
+    int64_t a0_first = 0, a1_first = 0;
+    if (rmine < nvecA) { a0_first = Ap[rmine]; a1_first = Ap[rmine + 1]; }
+    if (plain && end - start == DOT_TILE) {
+        // whole tile: all index loads in flight together, then all gathers (one wait each, not one per entry)
+        int64_t k[DOT_TILE_ITEMS]; X av[DOT_TILE_ITEMS], bv[DOT_TILE_ITEMS];
 #pragma unroll
-    for (int it = 0; it < DOT_TILE_ITEMS; it++) {
-        const int idx = it * DOT_TILE_THREADS + tid;
-        const int64_t p = start + idx;
-        if (p < end) {
-            const int64_t k = __builtin_nontemporal_load(&Ai[p]);   // streamed once: keep the cache for B
-            const bool ok = !B.b || B.b[boff + k];
-            Z t = Z();
-            if (ok) t = sr.mult(((apat) ? X() : __builtin_nontemporal_load(&Ax[A_iso ? 0 : p])), load_x<X>(Bx, boff + k, B.iso, bpat), 0, k, j);
-            prod[idx] = t;
-            have[idx] = ok;
+        for (int it = 0; it < DOT_TILE_ITEMS; it++)           // streamed once: keep the cache for B
+            k[it] = __builtin_nontemporal_load(&Ai[start + it * DOT_TILE_THREADS + tid]);
+#pragma unroll
+        for (int it = 0; it < DOT_TILE_ITEMS; it++)
+            av[it] = apat ? X() : __builtin_nontemporal_load(&Ax[A_iso ? 0 : start + it * DOT_TILE_THREADS + tid]);
+#pragma unroll
+        for (int it = 0; it < DOT_TILE_ITEMS; it++) bv[it] = load_x<X>(Bx, boff + k[it], B.iso, bpat);
+#pragma unroll
+        for (int it = 0; it < DOT_TILE_ITEMS; it++) prod[it * DOT_TILE_THREADS + tid] = sr.mult(av[it], bv[it], 0, k[it], j);
+    } else {
+#pragma unroll
+        for (int it = 0; it < DOT_TILE_ITEMS; it++) {
+            const int idx = it * DOT_TILE_THREADS + tid;
+            const int64_t p = start + idx;
+            if (p < end) {
+                const int64_t k = __builtin_nontemporal_load(&Ai[p]);
+                const bool ok = plain || B.b[boff + k];
+                Z t = Z();
+                if (ok) t = sr.mult(((apat) ? X() : __builtin_nontemporal_load(&Ax[A_iso ? 0 : p])), load_x<X>(Bx, boff + k, B.iso, bpat), 0, k, j);
+                prod[idx] = t;
+                have[idx] = ok;
+            }
         }
     }
     __syncthreads();
-    if (Ap[r0 + 1] >= end) {                                  // the tile lies inside one long row
+    if (next0 >= end) {                                       // the tile lies inside one long row
         Z acc = sr.identity(); int found = 0;
         for (int idx = tid; idx < (int)(end - start); idx += DOT_TILE_THREADS)
-            if (have[idx]) { acc = found ? sr.add(acc, prod[idx]) : prod[idx]; found = 1; }
+            if (plain || have[idx]) { acc = found ? sr.add(acc, prod[idx]) : prod[idx]; found = 1; }
         group_reduce(sr, acc, found, 64);
         if ((tid & 63) == 0) { part[tid >> 6] = acc; pfound[tid >> 6] = found; }
         __syncthreads();
         if (tid == 0) {
             Z r = sr.identity(); int f = 0;
             for (int w = 0; w < DOT_TILE_THREADS / 64; w++) if (pfound[w]) { r = f ? sr.add(r, part[w]) : part[w]; f = 1; }
-            const bool shared = Ap[r0] < start || Ap[r0 + 1] > end;
+            const bool shared = a0_first < start || next0 > end;      // thread 0 holds Ap[r0]
             if (f) dot_commit<S, MODE>(sr, M, r0, j, cvlen, r, shared, Cx, Cb);
         }
         return;
     }
-    for (int64_t r = r0 + tid; r < nvecA; r += DOT_TILE_THREADS) {
-        const int64_t a0 = Ap[r], a1 = Ap[r + 1];
+    // one thread per row for short segments; long ones (a hub row inside the tile) are queued for whole waves
+    for (int64_t r = rmine; r < nvecA; r += DOT_TILE_THREADS) {
+        const int64_t a0 = (r == rmine) ? a0_first : Ap[r], a1 = (r == rmine) ? a1_first : Ap[r + 1];
         if (a0 >= end) break;                                 // past the last row of the tile
         const int lo = (int)((a0 > start ? a0 : start) - start), hi = (int)((a1 < end ? a1 : end) - start);
+        if (hi - lo > DOT_SEG_SERIAL) { longq[atomicAdd(&nlongq, 1)] = (int)(r - r0); continue; }
         Z acc = sr.identity(); int found = 0;
         for (int idx = lo; idx < hi; idx++)
-            if (have[idx]) { acc = found ? sr.add(acc, prod[idx]) : prod[idx]; found = 1; }
+            if (plain || have[idx]) { acc = found ? sr.add(acc, prod[idx]) : prod[idx]; found = 1; }
         if (found) dot_commit<S, MODE>(sr, M, r, j, cvlen, acc, a0 < start || a1 > end, Cx, Cb);
+    }
+    __syncthreads();
+    const int nq = nlongq, lane = tid & 63;
+    for (int q = tid >> 6; q < nq; q += DOT_TILE_THREADS / 64) {
+        const int64_t r = r0 + longq[q];
+        const int64_t a0 = Ap[r], a1 = Ap[r + 1];
+        const int lo = (int)((a0 > start ? a0 : start) - start), hi = (int)((a1 < end ? a1 : end) - start);
+        Z acc = sr.identity(); int found = 0;
+        for (int idx = lo + lane; idx < hi; idx += 64)
+            if (plain || have[idx]) { acc = found ? sr.add(acc, prod[idx]) : prod[idx]; found = 1; }
+        group_reduce(sr, acc, found, 64);
+        if (lane == 0 && found) dot_commit<S, MODE>(sr, M, r, j, cvlen, acc, a0 < start || a1 > end, Cx, Cb);
     }
 }
 
@@ -286,7 +328,7 @@ static gba_info dot_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask_c
         GBA_OK(Cb.alloc((size_t)(cvlen * cvdim > 0 ? cvlen * cvdim : 1)));
         GBA_OK(Cx.alloc((size_t)(cvlen * cvdim > 0 ? cvlen * cvdim : 1) * zsize));
     }
-    DevBuf nlong, long_list;
+    DevBuf nlong, long_list, tile_rows;
     GBA_OK(nlong.alloc(4));
     GBA_OK(long_list.alloc((size_t)(A->nvec > 0 ? A->nvec : 1) * 8));
     GBA_HIP(hipMemsetAsync(nlong.p, 0, 4, st));
@@ -308,9 +350,15 @@ static gba_info dot_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask_c
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(fill_kernel<Z>), dim3((unsigned)fb), dim3(256), 0, st,
                                            reinterpret_cast<Z *>(cx), cn, sr.identity());
                     }
-                    dim3 tgrid((unsigned)ceil_div(A->nvals, DOT_TILE), (unsigned)cvdim);
+                    const int64_t ntiles = ceil_div(A->nvals, DOT_TILE);
+                    GBA_OK(tile_rows.alloc((size_t)ntiles * 8));
+                    int64_t rb = ceil_div(A->nvec, 256); if (rb > 8192) rb = 8192; if (rb < 1) rb = 1;
+                    hipLaunchKernelGGL(dot_tile_rows_kernel, dim3((unsigned)rb), dim3(256), 0, st, A->nvec, A->p,
+                                       (int64_t)DOT_TILE, tile_rows.as<int64_t>());
+                    dim3 tgrid((unsigned)ntiles, (unsigned)cvdim);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(dot_tile_kernel<S, MODE>), tgrid, dim3(DOT_TILE_THREADS), 0, st, sr,
-                                       A->nvec, A->p, A->i, A->x, A->iso, Bv, mv, reinterpret_cast<Z *>(cx), cb, cvlen);
+                                       A->nvec, A->p, A->i, A->x, A->iso, Bv, mv, reinterpret_cast<Z *>(cx), cb, cvlen,
+                                       tile_rows.as<int64_t>());
                 } else if (MODE == 1) {
                     GBA_HIP(hipMemsetAsync(cb, 0, (size_t)(cvlen * cvdim), st));
                 }
@@ -387,6 +435,278 @@ saxpy_sd_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64
     }
 }
 
+static unsigned grid_for(int64_t n) { int64_t b = ceil_div(n, 256); if (b > 8192) b = 8192; if (b < 1) b = 1; return (unsigned)b; }
+
+// ---- saxpy4 by destination bins ------------------------------------------------------------------
+// The scatter above sends one atomic per product to memory; atomics are carried out at the memory side
+// (about 6e9 a second, far fewer on a popular destination), which leaves y' += x'*A of a large graph two
+// orders of magnitude short of the memory rate.  The reference keeps a private workspace per task and
+// reduces the workspaces afterwards (Source/Template/GB_AxB_saxpy4_template.c:429-445); the same idea
+// here, shaped for the memory system:
+//   1  bin_count     every tile of BIN_TILE entries counts its destinations per bin of 2^shift indices
+//   2  (prefix sum of the bin-major count table = where each tile writes inside each bin)
+//   3  bin_scatter   the tile forms its products, sorts them by bin in LDS and writes (index, value) pairs
+//                    in runs, so every bin ends up contiguous
+//   4  bin_reduce    one workgroup per chunk of a bin sums the pairs into an LDS panel (LDS atomics) and
+//                    adds the panel to C, or parks it when the bin has several chunks
+//   5  bin_combine   sums the parked panels of such bins into C
+// Every byte moves in streams; no atomic leaves the CU.
+static constexpr int BIN_THREADS = 256, BIN_ITEMS = 16, BIN_TILE = BIN_THREADS * BIN_ITEMS;
+static constexpr int BIN_MAX = 2048;            // bins (the scan of the per-tile counts runs over 8 per thread)
+static constexpr int BIN_CHUNK = 32768;         // pairs per bin_reduce workgroup
+template <class Z> struct bin_shift { static constexpr int v = sizeof(Z) == 4 ? 14 : 13; };   // 64 KB panels
+
+// exclusive prefix sum of v[0..n) in LDS, n <= 8 * 256, by all 256 threads; v must be complete (barrier
+// before the call); returns the total after a closing barrier
+__device__ inline int block_scan_lds(int *v, int n, int *wsum) {
+    const int tid = threadIdx.x, per = (n + 255) / 256;
+    const int lo = tid * per, hi = (lo + per < n) ? lo + per : n;
+    int s = 0;
+    for (int q = lo; q < hi; q++) s += v[q];
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if ((tid & 63) >= d) inc += t; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    int run = inc - s;
+    for (int w = 0; w < (tid >> 6); w++) run += wsum[w];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    for (int q = lo; q < hi; q++) { const int c = v[q]; v[q] = run; run += c; }
+    __syncthreads();
+    return total;
+}
+
+__global__ void __launch_bounds__(BIN_THREADS)
+bin_count_kernel(int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai, int shift, int nb,
+                 int64_t nwg, int64_t *__restrict__ table) {
+    extern __shared__ int bin_dyn[];
+    int *h = bin_dyn;
+    const int tid = threadIdx.x;
+    const int64_t wg = blockIdx.x;
+    const int64_t start = Ap[0] + wg * BIN_TILE, pN = Ap[nvecA];
+    for (int b = tid; b < nb; b += BIN_THREADS) h[b] = 0;
+    __syncthreads();
+    int64_t k[BIN_ITEMS];
+#pragma unroll
+    for (int it = 0; it < BIN_ITEMS; it++) {
+        const int64_t p = start + it * BIN_THREADS + tid;
+        k[it] = (p < pN) ? Ai[p] : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < BIN_ITEMS; it++) if (k[it] >= 0) atomicAdd(&h[k[it] >> shift], 1);
+    __syncthreads();
+    for (int b = tid; b < nb; b += BIN_THREADS) table[(int64_t)b * nwg + wg] = h[b];      // bin-major
+}
+
+template <class S>
+__global__ void __launch_bounds__(BIN_THREADS)
+bin_scatter_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                   const void *__restrict__ Ax_, bool A_iso, DenseView B, int64_t j,
+                   const int64_t *__restrict__ tile_row, int shift, int nb, int64_t nwg,
+                   const int64_t *__restrict__ table, uint16_t *__restrict__ pair_idx,
+                   typename S::z_t *__restrict__ pair_val) {
+    using X = typename S::x_t; using Z = typename S::z_t;
+    extern __shared__ int bin_dyn[];
+    int *lstart = bin_dyn, *delta = bin_dyn + nb;            // per bin: first slot in the sorted tile; global - local
+    __shared__ int wsum[4];
+    __shared__ int scol[BIN_TILE];
+    __shared__ __align__(8) unsigned char vbuf[BIN_TILE * (sizeof(X) > sizeof(Z) ? sizeof(X) : sizeof(Z))];
+    __shared__ int longq[BIN_TILE / DOT_SEG_SERIAL + 2];
+    __shared__ int nlongq;
+    X *xs = reinterpret_cast<X *>(vbuf);                      // B(k,j) per entry, then (after a barrier) ...
+    Z *sval = reinterpret_cast<Z *>(vbuf);                    // ... the products in bin order
+    const X *Ax = reinterpret_cast<const X *>(Ax_);
+    const X *Bx = reinterpret_cast<const X *>(B.x);
+    const int tid = threadIdx.x;
+    const int64_t wg = blockIdx.x;
+    const int64_t pN = Ap[nvecA];
+    const int64_t start = Ap[0] + wg * BIN_TILE;
+    if (start >= pN) return;                                  // uniform
+    const int64_t end = (start + BIN_TILE < pN) ? start + BIN_TILE : pN;
+    const int ntile = (int)(end - start);
+    const int64_t r0 = tile_row[wg];
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+    for (int b = tid; b < nb; b += BIN_THREADS) { lstart[b] = 0; delta[b] = (int)table[(int64_t)b * nwg + wg]; }
+    if (tid == 0) nlongq = 0;
+    int col[BIN_ITEMS]; X av[BIN_ITEMS];
+#pragma unroll
+    for (int it = 0; it < BIN_ITEMS; it++) {
+        const int idx = it * BIN_THREADS + tid;
+        col[it] = (idx < ntile) ? (int)__builtin_nontemporal_load(&Ai[start + idx]) : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < BIN_ITEMS; it++) {
+        const int idx = it * BIN_THREADS + tid;
+        av[it] = (apat || idx >= ntile) ? X() : __builtin_nontemporal_load(&Ax[A_iso ? 0 : start + idx]);
+    }
+    __syncthreads();
+    // xs[idx] = B(k,j) of the vector k that owns entry idx: a thread per vector, whole waves for long segments
+    const int64_t boff = j * B.vlen;
+    for (int64_t r = r0 + tid; r < nvecA; r += BIN_THREADS) {
+        const int64_t a0 = Ap[r], a1 = Ap[r + 1];
+        if (a0 >= end) break;
+        const int lo = (int)((a0 > start ? a0 : start) - start), hi = (int)((a1 < end ? a1 : end) - start);
+        if (hi - lo > DOT_SEG_SERIAL) { longq[atomicAdd(&nlongq, 1)] = (int)(r - r0); continue; }
+        if (hi > lo) {
+            const X xv = load_x<X>(Bx, boff + r, B.iso, bpat);
+            for (int idx = lo; idx < hi; idx++) xs[idx] = xv;
+        }
+    }
+    __syncthreads();
+    {
+        const int nq = nlongq, lane = tid & 63;
+        for (int q = tid >> 6; q < nq; q += BIN_THREADS / 64) {
+            const int64_t r = r0 + longq[q];
+            const int64_t a0 = Ap[r], a1 = Ap[r + 1];
+            const int lo = (int)((a0 > start ? a0 : start) - start), hi = (int)((a1 < end ? a1 : end) - start);
+            const X xv = load_x<X>(Bx, boff + r, B.iso, bpat);
+            for (int idx = lo + lane; idx < hi; idx += 64) xs[idx] = xv;
+        }
+    }
+    __syncthreads();
+    int rank[BIN_ITEMS]; Z pv[BIN_ITEMS];
+#pragma unroll
+    for (int it = 0; it < BIN_ITEMS; it++) {
+        rank[it] = 0; pv[it] = Z();
+        if (col[it] >= 0) {
+            rank[it] = atomicAdd(&lstart[col[it] >> shift], 1);
+            pv[it] = sr.mult(av[it], xs[it * BIN_THREADS + tid], 0, 0, j);
+        }
+    }
+    __syncthreads();
+    block_scan_lds(lstart, nb, wsum);
+    for (int b = tid; b < nb; b += BIN_THREADS) delta[b] -= lstart[b];
+#pragma unroll
+    for (int it = 0; it < BIN_ITEMS; it++)
+        if (col[it] >= 0) { const int q = lstart[col[it] >> shift] + rank[it]; scol[q] = col[it]; sval[q] = pv[it]; }
+    __syncthreads();
+    const int low = (1 << shift) - 1;
+    for (int q = tid; q < ntile; q += BIN_THREADS) {
+        const int c = scol[q];
+        const int64_t dst = (int64_t)delta[c >> shift] + q;
+        pair_idx[dst] = (uint16_t)(c & low);
+        pair_val[dst] = sval[q];
+    }
+}
+
+// chunk_base[b] = number of bin_reduce workgroups of the bins before b; chunk_base[nb] = all of them
+__global__ void __launch_bounds__(256)
+bin_chunks_kernel(int nb, int64_t nwg, const int64_t *__restrict__ table, int *__restrict__ chunk_base) {
+    __shared__ int v[BIN_MAX];
+    __shared__ int wsum[4];
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        const int64_t cnt = table[(int64_t)(b + 1) * nwg] - table[(int64_t)b * nwg];
+        v[b] = (int)((cnt + BIN_CHUNK - 1) / BIN_CHUNK);
+    }
+    __syncthreads();
+    const int total = block_scan_lds(v, nb, wsum);
+    for (int b = threadIdx.x; b < nb; b += 256) chunk_base[b] = v[b];
+    if (threadIdx.x == 0) chunk_base[nb] = total;
+}
+
+template <class S>
+__global__ void __launch_bounds__(256)
+bin_reduce_kernel(S sr, int shift, int nb, int64_t nwg, const int64_t *__restrict__ table,
+                  const int *__restrict__ chunk_base, const uint16_t *__restrict__ pair_idx,
+                  const typename S::z_t *__restrict__ pair_val, typename S::z_t *__restrict__ Cx, int64_t cvlen,
+                  typename S::z_t *__restrict__ parked) {
+    using Z = typename S::z_t;
+    extern __shared__ __align__(8) unsigned char bin_panel[];
+    Z *panel = reinterpret_cast<Z *>(bin_panel);
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (w >= chunk_base[nb]) return;                          // uniform
+    int lo = 0, hi = nb - 1;                                  // the bin of chunk w: largest b with chunk_base[b] <= w
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chunk_base[mid] <= w) lo = mid; else hi = mid - 1; }
+    const int b = lo, first = chunk_base[b], nch = chunk_base[b + 1] - first;
+    const int64_t s = table[(int64_t)b * nwg] + (int64_t)(w - first) * BIN_CHUNK;
+    const int64_t bend = table[(int64_t)(b + 1) * nwg];
+    const int64_t e = (s + BIN_CHUNK < bend) ? s + BIN_CHUNK : bend;
+    const int width = 1 << shift;
+    const Z id = sr.identity();
+    for (int c = tid; c < width; c += 256) panel[c] = id;
+    __syncthreads();
+    int64_t q = s + tid;
+    for (; q + 3 * 256 < e; q += 4 * 256) {                   // four pairs in flight per thread
+        const uint16_t c0 = pair_idx[q], c1 = pair_idx[q + 256], c2 = pair_idx[q + 512], c3 = pair_idx[q + 768];
+        const Z v0 = pair_val[q], v1 = pair_val[q + 256], v2 = pair_val[q + 512], v3 = pair_val[q + 768];
+        sr.atomic(&panel[c0], v0); sr.atomic(&panel[c1], v1); sr.atomic(&panel[c2], v2); sr.atomic(&panel[c3], v3);
+    }
+    for (; q < e; q += 256) sr.atomic(&panel[pair_idx[q]], pair_val[q]);
+    __syncthreads();
+    if (nch == 1) {
+        const int64_t base = (int64_t)b << shift;
+        for (int c = tid; c < width; c += 256) {
+            const Z v = panel[c];
+            if (base + c < cvlen && !bits_equal<Z>(v, id)) Cx[base + c] = sr.add(Cx[base + c], v);
+        }
+    } else {
+        Z *out = parked + (int64_t)w * width;
+        for (int c = tid; c < width; c += 256) out[c] = panel[c];
+    }
+}
+
+template <class S>
+__global__ void __launch_bounds__(256)
+bin_combine_kernel(S sr, int shift, int64_t cvlen, const int *__restrict__ chunk_base,
+                   const typename S::z_t *__restrict__ parked, typename S::z_t *__restrict__ Cx) {
+    using Z = typename S::z_t;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t width = (int64_t)1 << shift;
+    for (; i < cvlen; i += stride) {
+        const int b = (int)(i >> shift);
+        const int first = chunk_base[b], nch = chunk_base[b + 1] - first;
+        if (nch <= 1) continue;
+        const Z *src = parked + (int64_t)first * width + (i & (width - 1));
+        Z acc = src[0];
+        for (int ch = 1; ch < nch; ch++) acc = sr.add(acc, src[(int64_t)ch * width]);
+        Cx[i] = sr.add(Cx[i], acc);
+    }
+}
+
+// C(:,j) += A * B(:,j) for every j, C full of the monoid's type, B full; false when the shape does not fit
+template <class S>
+static gba_info saxpy4_binned(S sr, const gba_matrix *A, const DenseView &Bv, int64_t cvlen, int64_t cvdim,
+                              typename S::z_t *cx, hipStream_t st, bool *done) {
+    using Z = typename S::z_t;
+    *done = false;
+    constexpr int shift = bin_shift<Z>::v;
+    const int64_t nnz = A->nvals, nb64 = ceil_div(cvlen, (int64_t)1 << shift);
+    if (Bv.b || nnz < ((int64_t)1 << 20) || nnz >= ((int64_t)1 << 31) || cvlen >= ((int64_t)1 << 31) ||
+        nb64 > BIN_MAX || cvdim > 8) return GBA_SUCCESS;
+    const int nb = (int)nb64;
+    const int64_t nwg = ceil_div(nnz, BIN_TILE), ncell = (int64_t)nb * nwg;
+    const int64_t maxchunks = ceil_div(nnz, BIN_CHUNK) + nb;
+    DevBuf table, tile_rows, chunk_base, pidx, pval, parked;
+    GBA_OK(table.alloc((size_t)(ncell + 1) * 8));
+    GBA_OK(tile_rows.alloc((size_t)nwg * 8));
+    GBA_OK(chunk_base.alloc((size_t)(nb + 1) * 4));
+    GBA_OK(pidx.alloc((size_t)nnz * 2));
+    GBA_OK(pval.alloc((size_t)nnz * sizeof(Z)));
+    GBA_OK(parked.alloc((size_t)maxchunks * sizeof(Z) << shift));
+    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)nwg), dim3(BIN_THREADS), (size_t)nb * 4, st, A->nvec, A->p, A->i,
+                       shift, nb, nwg, table.as<int64_t>());
+    GBA_OK(dev_cumsum_i64(table.as<int64_t>(), ncell, st));
+    int64_t rb = ceil_div(A->nvec, 256); if (rb > 8192) rb = 8192; if (rb < 1) rb = 1;
+    hipLaunchKernelGGL(dot_tile_rows_kernel, dim3((unsigned)rb), dim3(256), 0, st, A->nvec, A->p, (int64_t)BIN_TILE,
+                       tile_rows.as<int64_t>());
+    hipLaunchKernelGGL(bin_chunks_kernel, dim3(1), dim3(256), 0, st, nb, nwg, table.as<int64_t>(), chunk_base.as<int>());
+    for (int64_t j = 0; j < cvdim; j++) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_scatter_kernel<S>), dim3((unsigned)nwg), dim3(BIN_THREADS), (size_t)nb * 8, st,
+                           sr, A->nvec, A->p, A->i, A->x, A->iso, Bv, j, tile_rows.as<int64_t>(), shift, nb, nwg,
+                           table.as<int64_t>(), pidx.as<uint16_t>(), pval.as<Z>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_reduce_kernel<S>), dim3((unsigned)maxchunks), dim3(256), sizeof(Z) << shift, st,
+                           sr, shift, nb, nwg, table.as<int64_t>(), chunk_base.as<int>(), pidx.as<uint16_t>(), pval.as<Z>(),
+                           cx + j * cvlen, cvlen, parked.as<Z>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_combine_kernel<S>), dim3(grid_for(cvlen)), dim3(256), 0, st, sr, shift, cvlen,
+                           chunk_base.as<int>(), parked.as<Z>(), cx + j * cvlen);
+    }
+    GBA_HIP(hipGetLastError());
+    GBA_HIP(hipStreamSynchronize(st));                        // the buffers above go back to the pool on return
+    *done = true;
+    return GBA_SUCCESS;
+}
+
 // widen / narrow between the stored type and the accumulator type (8/16-bit and bool)
 template <class Z, class ACC>
 __global__ void widen_kernel(const Z *__restrict__ in, ACC *__restrict__ out, int64_t n) {
@@ -406,7 +726,6 @@ __global__ void fill_kernel(ACC *p, int64_t n, ACC v) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; idx < n; idx += stride) p[idx] = v;
 }
-static unsigned grid_for(int64_t n) { int64_t b = ceil_div(n, 256); if (b > 8192) b = 8192; if (b < 1) b = 1; return (unsigned)b; }
 
 template <int MODE>
 static gba_info saxpy_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
@@ -449,6 +768,11 @@ static gba_info saxpy_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask
                 if (MODE == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(widen_kernel<Z, ACC>), dim3(grid_for(cn)), dim3(256), 0, st, cx, acc, cn);
             }
             if (MODE == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(fill_kernel<ACC>), dim3(grid_for(cn)), dim3(256), 0, st, acc, cn, (ACC)sr.identity());
+            if constexpr (MODE == 0 && dot_tile_ok<S>::v) {
+                bool done = false;
+                GBA_OK(saxpy4_binned<S>(sr, A, Bv, cvlen, cvdim, cx, st, &done));
+                if (done) return GBA_SUCCESS;
+            }
             dim3 grid((unsigned)ceil_div(A->nvec * lpr, 256), (unsigned)cvdim);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(saxpy_sd_kernel<S, MODE>), grid, dim3(256), 0, st, sr, A->nvec, A->p, A->i,
                                A->x, A->iso, Bv, mv, lpr, acc, Cb.as<int8_t>(), cvlen);

@@ -10,15 +10,35 @@
 namespace gba {
 
 // --------------------------------------------------------------- count ones --
+// Eight bitmap bytes per load; one atomic per workgroup (atomics on one address serialise at the
+// memory side, about 12 ns each, so a launch keeps them to a few hundred).
+__device__ inline int nonzero_bytes(uint64_t w) {
+    const uint64_t low7 = 0x7f7f7f7f7f7f7f7fULL;
+    return __popcll((w | ((w & low7) + low7)) & ~low7);
+}
+
 __global__ void __launch_bounds__(256)
 count_ones_kernel(const int8_t *__restrict__ b, int64_t n, unsigned long long *__restrict__ out) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long part[4];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t head = (int64_t)((8 - (reinterpret_cast<uintptr_t>(b) & 7)) & 7);   // bytes before the first aligned word
+    if (head > n) head = n;
+    const int64_t nwords = (n - head) >> 3;
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(b + head);
     unsigned long long c = 0;
-    for (; idx < n; idx += stride) c += (b[idx] != 0);
+    for (int64_t q = tid; q < nwords; q += stride) c += nonzero_bytes(w[q]);
+    const int64_t tail = head + (nwords << 3);
+    if (tid < head) c += (b[tid] != 0);
+    if (tid < n - tail) c += (b[tail + tid] != 0);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = part[0] + part[1] + part[2] + part[3];
+        if (c) atomicAdd(out, c);
+    }
 }
 
 gba_info dev_count_ones(const int8_t *b, int64_t n, int64_t *out) {
@@ -27,7 +47,7 @@ gba_info dev_count_ones(const int8_t *b, int64_t n, int64_t *out) {
     hipStream_t st = ctx().stream;
     DevBuf o; GBA_OK(o.alloc(8));
     GBA_HIP(hipMemsetAsync(o.p, 0, 8, st));
-    int64_t blocks = ceil_div(n, 256); if (blocks > 4096) blocks = 4096;
+    int64_t blocks = ceil_div(n, 256 * 8 * 8); if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(count_ones_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b, n, o.as<unsigned long long>());
     GBA_HIP(hipMemcpyAsync(out, o.p, 8, hipMemcpyDeviceToHost, st));
     GBA_HIP(hipStreamSynchronize(st));

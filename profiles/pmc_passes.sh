@@ -1,7 +1,7 @@
 #!/bin/bash
 # Hardware-counter passes over one bench command on the GPU box (one rocprofv3 run per pass: the
 # counter blocks hold 8 SQ, 4 TCC, 4 TCP, 2 TA, 2 GRBM counters at a time).
-#   profiles/pmc_passes.sh <out-dir under gpurun_out> <bench.py arguments...>
+#   profiles/pmc_passes.sh <out-dir under gpurun_out> <bench.py arguments...>     (GBA_PMC_PROG=bench_paths.py runs that instead)
 # Each pass leaves <out>/<pass>/*counter_collection.csv; profiles/pmc_summary.py sums them per kernel.
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
@@ -17,5 +17,5 @@ PASS[write]="WRITE_SIZE"
 for p in ${GBA_PMC_PASSES:-sq1 sq2 mem occ fetch write}; do
     echo "[pmc] pass $p: ${PASS[$p]}"
     timeout -s KILL 240 rocprofv3 --pmc ${PASS[$p]} --kernel-trace -d "$OUT/$p" --output-format csv -- \
-        python3 "$GRAFT_REPO_ROOT/bench.py" "$@" > "$OUT/$p.json" 2> "$OUT/$p.err" || { echo "[pmc] pass $p failed"; tail -5 "$OUT/$p.err"; exit 1; }
+        python3 "$GRAFT_REPO_ROOT/${GBA_PMC_PROG:-bench.py}" "$@" > "$OUT/$p.json" 2> "$OUT/$p.err" || { echo "[pmc] pass $p failed"; tail -5 "$OUT/$p.err"; exit 1; }
 done

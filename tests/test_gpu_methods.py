@@ -174,6 +174,32 @@ def test_saxpy4_in_place(gba, sr, t, bkind):
     _free(dA, dB, dC)
 
 
+@pytest.mark.parametrize("sr,t", [("PLUS_TIMES_FP32", Type.FP32), ("PLUS_TIMES_FP64", Type.FP64), ("MIN_PLUS_FP64", Type.FP64),
+                                  ("PLUS_TIMES_INT64", Type.INT64), ("BXOR_BAND_UINT32", Type.UINT32),
+                                  ("MAX_SECOND_INT32", Type.INT32)])
+def test_saxpy4_large_goes_through_destination_bins(gba, sr, t):
+    """More than 2^20 entries and B full: products are binned by destination and summed in LDS panels.
+    The matrix has a vector longer than a tile, a run of empty vectors, a destination hit 30000 times,
+    bins with several chunks and a bin with one; small integer values keep every sum exact."""
+    from graphblas_amd.binding import NP_TYPES
+    rng = np.random.default_rng(21)
+    n, inner = 200_000, 150_000
+    dest = np.concatenate([rng.integers(0, 60_000, 900_000), rng.integers(0, 180_000, 400_000),
+                           rng.integers(180_000, n, 20_000), np.full(30_000, 7), rng.choice(n, 50_000, replace=False)])
+    k = np.concatenate([rng.integers(0, 100_000, 1_320_000), rng.choice(100_000, 30_000, replace=False), np.full(50_000, 5)])
+    S = sp.coo_matrix((rng.integers(1, 3, len(k)).astype(np.float64), (dest, k)), shape=(n, inner)).tocsc()
+    S.sum_duplicates(); S.data = np.minimum(S.data, 3)
+    assert S.nnz > (1 << 20)
+    A = Matrix.from_scipy(S, type=t, by_row=False)
+    B = Matrix.dense(rng.integers(0, 3, (inner, 2)).astype(NP_TYPES[t]), by_row=False)
+    C0 = Matrix.dense(rng.integers(0, 3, (n, 2)).astype(NP_TYPES[t]), by_row=False)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    rep = gba.AxB_saxpy4(dC, dA, dB, sr)
+    assert rep is not None
+    assert_same(dC.to_host(), oracle.saxpy4(C0, A, B, sr), exact=True, what=sr)
+    _free(dA, dB, dC)
+
+
 @pytest.mark.parametrize("sr,t", [("PLUS_TIMES_FP64", Type.FP64), ("MIN_PLUS_INT32", Type.INT32), ("MAX_FIRST_FP32", Type.FP32)])
 @pytest.mark.parametrize("akind", ["full", "bitmap"])
 def test_saxpy5_in_place(gba, sr, t, akind):
