@@ -42,14 +42,16 @@ def timed(fn, iters, warmup=2):
 def spmv(args):
     import graphblas_amd as g
     from graphblas_amd import gen, Matrix, Type
-    A = gen.rmat(args.scale, 16, seed=42, type=Type.FP32)            # CSR
+    fp = {"fp32": (Type.FP32, np.float32, "FP32", 4), "fp64": (Type.FP64, np.float64, "FP64", 8)}[args.type]
+    A = gen.rmat(args.scale, 16, seed=42, type=fp[0])                # CSR
     n, nnz = A.nrows, A.nvals
     rng = np.random.default_rng(1)
-    x = Matrix.full_vector((rng.random(n) + 0.5).astype(np.float32))
-    y0 = Matrix.full_vector(np.zeros(n, np.float32))
+    x = Matrix.full_vector((rng.random(n) + 0.5).astype(fp[1]))
+    y0 = Matrix.full_vector(np.zeros(n, fp[1]))
     dA, dx, dy = A.to_device(), x.to_device(), y0.to_device()
-    bytes_spmv = nnz * (8 + 4) + (n + 1) * 8 + n * 4 + n * 4        # int64 indices as handed over
-    base = dict(workload=f"RMAT-{args.scale} ef=16 seed=42 SpMV PLUS_TIMES_FP32, CSR int64", n=n, nnz=nnz,
+    bytes_spmv = nnz * (8 + fp[3]) + (n + 1) * 8 + 2 * n * fp[3]    # int64 indices as handed over
+    PLUS, SR = "PLUS_" + fp[2], "PLUS_TIMES_" + fp[2]
+    base = dict(workload=f"RMAT-{args.scale} ef=16 seed=42 SpMV {SR}, CSR int64", n=n, nnz=nnz,
                 algorithmic_bytes=bytes_spmv, unit="GB/s", peak=HBM_PEAK_GBS)
 
     def run(label, fn, extra_bytes=0):
@@ -59,15 +61,15 @@ def spmv(args):
         emit(case=label, method=g.Method.NAMES[rep.method], ms=round(ms, 4), wall_ms=round(wall, 4),
              achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4), GFLOPs=round(2 * nnz / ms / 1e6, 1), **base)
 
-    run("y += A*x (accum PLUS, y full)", lambda: g.mxv(dy, None, "PLUS_FP32", "PLUS_TIMES_FP32", dA, dx))
+    run("y += A*x (accum PLUS, y full)", lambda: g.mxv(dy, None, PLUS, SR, dA, dx))
 
     def dot2_call():
-        w = g.DeviceMatrix.upload(Matrix.sparse_vector(n, np.zeros(0, np.int64), np.zeros(0, np.float32)))
-        rep = g.mxv(w, None, None, "PLUS_TIMES_FP32", dA, dx)
+        w = g.DeviceMatrix.upload(Matrix.sparse_vector(n, np.zeros(0, np.int64), np.zeros(0, fp[1])))
+        rep = g.mxv(w, None, None, SR, dA, dx)
         w.free()
         return rep
     run("y = A*x (no accum, y bitmap)", dot2_call, extra_bytes=n)
-    run("y' += x'*A (vxm, scatter)", lambda: g.vxm(dy, None, "PLUS_FP32", "PLUS_TIMES_FP32", dx, dA))
+    run("y' += x'*A (vxm, scatter)", lambda: g.vxm(dy, None, PLUS, SR, dx, dA))
     for d in (dA, dx, dy):
         d.free()
 
@@ -157,6 +159,7 @@ if __name__ == "__main__":
     ap.add_argument("what", choices=["spmv", "tricount", "bfs"])
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--type", choices=["fp32", "fp64"], default="fp32", help="spmv value type")
     a = ap.parse_args()
     import graphblas_amd as g
     g.init(0)

@@ -451,15 +451,66 @@ static unsigned grid_for(int64_t n) { int64_t b = ceil_div(n, 256); if (b > 8192
 //                    adds the panel to C, or parks it when the bin has several chunks
 //   5  bin_combine   sums the parked panels of such bins into C
 // Every byte moves in streams; no atomic leaves the CU.
-static constexpr int BIN_THREADS = 256, BIN_ITEMS = 16, BIN_TILE = BIN_THREADS * BIN_ITEMS;
-static constexpr int BIN_MAX = 2048;            // bins (the scan of the per-tile counts runs over 8 per thread)
+static constexpr int BIN_THREADS = 512;         // a tile is BIN_THREADS * ITEMS entries
+template <class S> struct bin_items { static constexpr int v = 8; };
+static constexpr int BIN_MAX = 2048;            // bins
 static constexpr int BIN_CHUNK = 32768;         // pairs per bin_reduce workgroup
-template <class Z> struct bin_shift { static constexpr int v = sizeof(Z) == 4 ? 14 : 13; };   // 64 KB panels
+static constexpr int BIN_WALK = 128;            // tiles one bin_scatter workgroup walks at most
+static constexpr int BIN_REDUCE_THREADS = 1024; // two such workgroups fill a CU: the panels take 64 KB of LDS each
+// The LDS panels hold floats as doubles: on gfx950 ds_add_f32 handles one lane at a time (80 ns per wave
+// instruction against 9 ns for ds_add_f64 and 6 ns for ds_add_u32, measured with random addresses), so a
+// float sum through LDS atomics is ten times faster in fp64, and rounds once at the end.
+template <class Z> struct bin_panel { using type = Z; };
+template <> struct bin_panel<float> { using type = double; };
+// Bins of 2^14 destinations whatever the type (64 KB panels of 4-byte sums, 128 KB of 8-byte ones): the
+// narrower the bins, the shorter the runs bin_scatter writes, and short runs are what it pays for.
+template <class Z> struct bin_shift { static constexpr int v = 14; };
 
-// exclusive prefix sum of v[0..n) in LDS, n <= 8 * 256, by all 256 threads; v must be complete (barrier
-// before the call); returns the total after a closing barrier
+#ifdef GBA_PANEL_TICKS                            // tuning build: per-phase stopwatch of bin_scatter (shader clocks)
+__device__ unsigned long long bin_ticks[16];
+#define BIN_TICK0 unsigned long long tk_ = __builtin_amdgcn_s_memtime()
+#define BIN_TICK(n) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        atomicAdd(&bin_ticks[n], t_ - tk_); tk_ = t_; } } while (0)
+#else
+#define BIN_TICK0
+#define BIN_TICK(n)
+#endif
+
+// Loads that the compiler does not see as memory instructions, each followed by its own wait.  For rarely
+// taken paths inside a software-pipelined loop: a compiler-visible load there makes every later register
+// reuse wait for all outstanding loads (it cannot tell whether that path ran), the prefetch included.
+__device__ inline void load_i64_pair_blocking(const int64_t *p, int64_t &lo, int64_t &hi) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
+    lo = (int64_t)(((uint64_t)r.y << 32) | r.x);
+    hi = (int64_t)(((uint64_t)r.w << 32) | r.z);
+}
+template <class T> __device__ inline T load_blocking(const T *p) {
+    if constexpr (sizeof(T) == 4) {
+        unsigned int r;
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
+        T t; __builtin_memcpy(&t, &r, 4); return t;
+    } else if constexpr (sizeof(T) == 8) {
+        unsigned long long r;
+        asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
+        T t; __builtin_memcpy(&t, &r, 8); return t;
+    } else {
+        return *p;
+    }
+}
+
+__device__ inline int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// workgroup barrier that waits for this wave's LDS traffic only: loads from memory issued earlier (a
+// prefetch for the next tile) stay in flight across it, which __syncthreads() would not allow
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// exclusive prefix sum of v[0..n) in LDS by all NT threads of the workgroup (wsum: NT / 64 ints); v must be
+// complete (barrier before the call); returns the total after a closing barrier
+template <int NT>
 __device__ inline int block_scan_lds(int *v, int n, int *wsum) {
-    const int tid = threadIdx.x, per = (n + 255) / 256;
+    const int tid = threadIdx.x, per = (n + NT - 1) / NT;
     const int lo = tid * per, hi = (lo + per < n) ? lo + per : n;
     int s = 0;
     for (int q = lo; q < hi; q++) s += v[q];
@@ -467,125 +518,220 @@ __device__ inline int block_scan_lds(int *v, int n, int *wsum) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if ((tid & 63) >= d) inc += t; }
     if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-    __syncthreads();
-    int run = inc - s;
-    for (int w = 0; w < (tid >> 6); w++) run += wsum[w];
-    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    lds_barrier();
+    int run = inc - s, total = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) { if (w < (tid >> 6)) run += wsum[w]; total += wsum[w]; }
     for (int q = lo; q < hi; q++) { const int c = v[q]; v[q] = run; run += c; }
-    __syncthreads();
+    lds_barrier();
     return total;
 }
 
+// One workgroup counts BIN_COUNT_TILES consecutive tiles, so that for every bin it writes that many adjacent
+// cells of the bin-major table at once (a full 64-byte line) instead of one 8-byte cell per tile.
+static constexpr int BIN_COUNT_TILES = 8;
+template <int BIN_ITEMS>
 __global__ void __launch_bounds__(BIN_THREADS)
 bin_count_kernel(int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai, int shift, int nb,
                  int64_t nwg, int64_t *__restrict__ table) {
+    constexpr int BIN_TILE = BIN_THREADS * BIN_ITEMS;
     extern __shared__ int bin_dyn[];
-    int *h = bin_dyn;
+    int *h = bin_dyn;                                         // h[b * BIN_COUNT_TILES + t]
     const int tid = threadIdx.x;
-    const int64_t wg = blockIdx.x;
-    const int64_t start = Ap[0] + wg * BIN_TILE, pN = Ap[nvecA];
-    for (int b = tid; b < nb; b += BIN_THREADS) h[b] = 0;
+    const int64_t wg0 = (int64_t)blockIdx.x * BIN_COUNT_TILES;
+    const int64_t p0 = Ap[0], pN = Ap[nvecA];
+    const int *Ai_lo = reinterpret_cast<const int *>(Ai);    // indices are below 2^31 here
+    for (int q = tid; q < nb * BIN_COUNT_TILES; q += BIN_THREADS) h[q] = 0;
     __syncthreads();
-    int64_t k[BIN_ITEMS];
+    for (int t = 0; t < BIN_COUNT_TILES; t++) {
+        const int64_t start = p0 + (wg0 + t) * BIN_TILE;
+        if (start >= pN) break;                               // uniform
+        int k[BIN_ITEMS];
 #pragma unroll
-    for (int it = 0; it < BIN_ITEMS; it++) {
-        const int64_t p = start + it * BIN_THREADS + tid;
-        k[it] = (p < pN) ? Ai[p] : -1;
+        for (int it = 0; it < BIN_ITEMS; it++) {
+            const int64_t p = start + it * BIN_THREADS + tid;
+            k[it] = (p < pN) ? __builtin_nontemporal_load(&Ai_lo[2 * p]) : -1;
+        }
+#pragma unroll
+        for (int it = 0; it < BIN_ITEMS; it++) if (k[it] >= 0) atomicAdd(&h[(k[it] >> shift) * BIN_COUNT_TILES + t], 1);
     }
-#pragma unroll
-    for (int it = 0; it < BIN_ITEMS; it++) if (k[it] >= 0) atomicAdd(&h[k[it] >> shift], 1);
     __syncthreads();
-    for (int b = tid; b < nb; b += BIN_THREADS) table[(int64_t)b * nwg + wg] = h[b];      // bin-major
+    for (int q = tid; q < nb * BIN_COUNT_TILES; q += BIN_THREADS) {
+        const int b = q / BIN_COUNT_TILES, t = q - b * BIN_COUNT_TILES;
+        if (wg0 + t < nwg) table[(int64_t)b * nwg + wg0 + t] = h[q];      // bin-major
+    }
 }
 
-template <class S>
-__global__ void __launch_bounds__(BIN_THREADS)
+// A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; while it sorts one tile in LDS the loads of
+// its next tile are already in flight (the memory round trip is several microseconds under load, longer
+// than the LDS work on a tile, and too few workgroups fit a CU to hide it by occupancy alone).
+template <class S, int BIN_ITEMS>
+__global__ void __launch_bounds__(BIN_THREADS, 4)      // four waves per SIMD = two workgroups per CU: at most 128 registers
 bin_scatter_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
                    const void *__restrict__ Ax_, bool A_iso, DenseView B, int64_t j,
                    const int64_t *__restrict__ tile_row, int shift, int nb, int64_t nwg,
                    const int64_t *__restrict__ table, uint16_t *__restrict__ pair_idx,
                    typename S::z_t *__restrict__ pair_val) {
     using X = typename S::x_t; using Z = typename S::z_t;
+    constexpr int BIN_TILE = BIN_THREADS * BIN_ITEMS;
+    constexpr int NLONG = BIN_TILE / DOT_SEG_SERIAL + 2, NGB = BIN_MAX / BIN_THREADS;
     extern __shared__ int bin_dyn[];
     int *lstart = bin_dyn, *delta = bin_dyn + nb;            // per bin: first slot in the sorted tile; global - local
-    __shared__ int wsum[4];
+    __shared__ int wsum[BIN_THREADS / 64];
     __shared__ int scol[BIN_TILE];
     __shared__ __align__(8) unsigned char vbuf[BIN_TILE * (sizeof(X) > sizeof(Z) ? sizeof(X) : sizeof(Z))];
-    __shared__ int longq[BIN_TILE / DOT_SEG_SERIAL + 2];
+    __shared__ int longlo[NLONG], longhi[NLONG];
+    __shared__ X longx[NLONG];
     __shared__ int nlongq;
     X *xs = reinterpret_cast<X *>(vbuf);                      // B(k,j) per entry, then (after a barrier) ...
     Z *sval = reinterpret_cast<Z *>(vbuf);                    // ... the products in bin order
     const X *Ax = reinterpret_cast<const X *>(Ax_);
     const X *Bx = reinterpret_cast<const X *>(B.x);
     const int tid = threadIdx.x;
-    const int64_t wg = blockIdx.x;
-    const int64_t pN = Ap[nvecA];
-    const int64_t start = Ap[0] + wg * BIN_TILE;
-    if (start >= pN) return;                                  // uniform
-    const int64_t end = (start + BIN_TILE < pN) ? start + BIN_TILE : pN;
-    const int ntile = (int)(end - start);
-    const int64_t r0 = tile_row[wg];
+    // Which tiles this workgroup walks.  Workgroups go to the eight XCDs in turn (blockIdx.x % 8), each XCD
+    // with its own L2: the tiles are cut into eight contiguous ranges, one per XCD, so that neighbouring
+    // tiles -- whose runs are neighbours inside every bin -- complete each other's cache lines in one L2.
+    int64_t tile, G, tile_end;
+    if (gridDim.x % 8 == 0) {
+        const int64_t per_xcd = ceil_div_dev(nwg, 8), xcd = blockIdx.x & 7;
+        tile = xcd * per_xcd + (blockIdx.x >> 3);
+        G = gridDim.x >> 3;
+        tile_end = (xcd + 1) * per_xcd < nwg ? (xcd + 1) * per_xcd : nwg;
+    } else {
+        tile = blockIdx.x; G = gridDim.x; tile_end = nwg;
+    }
+    if (tile >= tile_end) return;                             // uniform
+    const int64_t p0 = Ap[0], pN = Ap[nvecA];
     const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
-    for (int b = tid; b < nb; b += BIN_THREADS) { lstart[b] = 0; delta[b] = (int)table[(int64_t)b * nwg + wg]; }
-    if (tid == 0) nlongq = 0;
-    int col[BIN_ITEMS]; X av[BIN_ITEMS];
-#pragma unroll
-    for (int it = 0; it < BIN_ITEMS; it++) {
-        const int idx = it * BIN_THREADS + tid;
-        col[it] = (idx < ntile) ? (int)__builtin_nontemporal_load(&Ai[start + idx]) : -1;
-    }
-#pragma unroll
-    for (int it = 0; it < BIN_ITEMS; it++) {
-        const int idx = it * BIN_THREADS + tid;
-        av[it] = (apat || idx >= ntile) ? X() : __builtin_nontemporal_load(&Ax[A_iso ? 0 : start + idx]);
-    }
-    __syncthreads();
-    // xs[idx] = B(k,j) of the vector k that owns entry idx: a thread per vector, whole waves for long segments
     const int64_t boff = j * B.vlen;
-    for (int64_t r = r0 + tid; r < nvecA; r += BIN_THREADS) {
-        const int64_t a0 = Ap[r], a1 = Ap[r + 1];
-        if (a0 >= end) break;
-        const int lo = (int)((a0 > start ? a0 : start) - start), hi = (int)((a1 < end ? a1 : end) - start);
-        if (hi - lo > DOT_SEG_SERIAL) { longq[atomicAdd(&nlongq, 1)] = (int)(r - r0); continue; }
-        if (hi > lo) {
-            const X xv = load_x<X>(Bx, boff + r, B.iso, bpat);
-            for (int idx = lo; idx < hi; idx++) xs[idx] = xv;
-        }
-    }
-    __syncthreads();
-    {
-        const int nq = nlongq, lane = tid & 63;
-        for (int q = tid >> 6; q < nq; q += BIN_THREADS / 64) {
-            const int64_t r = r0 + longq[q];
-            const int64_t a0 = Ap[r], a1 = Ap[r + 1];
-            const int lo = (int)((a0 > start ? a0 : start) - start), hi = (int)((a1 < end ? a1 : end) - start);
-            const X xv = load_x<X>(Bx, boff + r, B.iso, bpat);
-            for (int idx = lo + lane; idx < hi; idx += 64) xs[idx] = xv;
-        }
-    }
-    __syncthreads();
-    int rank[BIN_ITEMS]; Z pv[BIN_ITEMS];
-#pragma unroll
-    for (int it = 0; it < BIN_ITEMS; it++) {
-        rank[it] = 0; pv[it] = Z();
-        if (col[it] >= 0) {
-            rank[it] = atomicAdd(&lstart[col[it] >> shift], 1);
-            pv[it] = sr.mult(av[it], xs[it * BIN_THREADS + tid], 0, 0, j);
-        }
-    }
-    __syncthreads();
-    block_scan_lds(lstart, nb, wsum);
-    for (int b = tid; b < nb; b += BIN_THREADS) delta[b] -= lstart[b];
-#pragma unroll
-    for (int it = 0; it < BIN_ITEMS; it++)
-        if (col[it] >= 0) { const int q = lstart[col[it] >> shift] + rank[it]; scol[q] = col[it]; sval[q] = pv[it]; }
-    __syncthreads();
     const int low = (1 << shift) - 1;
-    for (int q = tid; q < ntile; q += BIN_THREADS) {
-        const int c = scol[q];
-        const int64_t dst = (int64_t)delta[c >> shift] + q;
-        pair_idx[dst] = (uint16_t)(c & low);
-        pair_val[dst] = sval[q];
+    // the first vector of each tile this workgroup will walk, fetched once: the loads of a tile start from it
+    __shared__ int64_t myrow[BIN_WALK];
+    for (int64_t k = tid; k < BIN_WALK; k += BIN_THREADS) {
+        const int64_t t = tile + k * G;
+        myrow[k] = (t < tile_end) ? tile_row[t] : 0;
+    }
+    __syncthreads();
+    // indices are below 2^31 here: only their low words are loaded (a load whose upper half is dead makes the
+    // compiler reuse that register at once, and the reuse then has to wait for the load)
+    const int *Ai_lo = reinterpret_cast<const int *>(Ai);
+    const int64_t isomask = A_iso ? 0 : -1;                   // an iso A reads Ax[0] through the same vector loads
+    auto issue = [&](int64_t t, int64_t tr0, int (&c)[BIN_ITEMS], X (&a)[BIN_ITEMS], int64_t &a0, int64_t &a1, X &xv) {
+        const int64_t st = p0 + t * BIN_TILE;
+        const int64_t rm = tr0 + tid, rc = (rm < nvecA) ? rm : nvecA - 1;
+        a0 = Ap[rc]; a1 = Ap[rc + 1]; xv = load_x<X>(Bx, boff + rc, B.iso, bpat);
+#pragma unroll
+        for (int it = 0; it < BIN_ITEMS; it++) {
+            const int64_t p = st + it * BIN_THREADS + tid;
+            c[it] = __builtin_nontemporal_load(&Ai_lo[2 * (p < pN ? p : pN - 1)]);
+        }
+        if (!apat) {
+#pragma unroll
+            for (int it = 0; it < BIN_ITEMS; it++) {
+                const int64_t p = st + it * BIN_THREADS + tid;
+                a[it] = __builtin_nontemporal_load(&Ax[(p < pN ? p : pN - 1) & isomask]);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < BIN_ITEMS; it++) a[it] = X();
+        }
+    };
+
+    int walk = 0;
+    int col[BIN_ITEMS], ncol[BIN_ITEMS]; X av[BIN_ITEMS], nav[BIN_ITEMS];
+    int64_t a0_first, a1_first, na0_first, na1_first; X x_first, nx_first;
+    int64_t r0 = myrow[0];
+    issue(tile, r0, col, av, a0_first, a1_first, x_first);
+    while (true) {
+        BIN_TICK0;
+        const int64_t start = p0 + tile * BIN_TILE;
+        const int64_t end = (start + BIN_TILE < pN) ? start + BIN_TILE : pN;
+        const int ntile = (int)(end - start);
+        const bool more = tile + G < tile_end;
+        // this tile's place in every bin (needed late), then the next tile's loads: in that order, because a
+        // wait for a load also waits for every load issued before it.  The last tile fetches itself again.
+        int gb[NGB];
+#pragma unroll
+        for (int u = 0; u < NGB; u++) {
+            const int b = u * BIN_THREADS + tid;
+            gb[u] = (int)table[(int64_t)(b < nb ? b : nb - 1) * nwg + tile];
+        }
+        const int64_t nr0 = myrow[more ? walk + 1 : walk];
+        issue(more ? tile + G : tile, nr0, ncol, nav, na0_first, na1_first, nx_first);
+        for (int b = tid; b < nb; b += BIN_THREADS) lstart[b] = 0;
+        if (tid == 0) nlongq = 0;
+        lds_barrier();
+        BIN_TICK(0);
+        // xs[idx] = B(k,j) of the vector k that owns entry idx: a thread per vector, whole waves for long
+        // segments.  The first vector of each thread comes from the registers loaded a tile ago.
+        const int64_t rmine = r0 + tid;
+        auto spread = [&](int64_t a0, int64_t a1, X xv) {
+            const int lo = (int)((a0 > start ? a0 : start) - start), hi = (int)((a1 < end ? a1 : end) - start);
+            if (hi <= lo) return;
+            if (hi - lo > DOT_SEG_SERIAL) {
+                const int q = atomicAdd(&nlongq, 1);
+                longlo[q] = lo; longhi[q] = hi; longx[q] = xv;
+                return;
+            }
+            for (int idx = lo; idx < hi; idx++) xs[idx] = xv;
+        };
+        if (rmine < nvecA && a0_first < end) spread(a0_first, a1_first, x_first);
+        if (rmine + BIN_THREADS < nvecA && a1_first < end) {           // a tile of more than BIN_THREADS vectors
+            for (int64_t r = rmine + BIN_THREADS; r < nvecA; r += BIN_THREADS) {
+                int64_t a0, a1;
+                load_i64_pair_blocking(Ap + r, a0, a1);
+                if (a0 >= end) break;
+                spread(a0, a1, bpat ? X() : load_blocking<X>(&Bx[B.iso ? 0 : boff + r]));
+            }
+        }
+        lds_barrier();
+        BIN_TICK(1);
+        {
+            const int nq = nlongq, lane = tid & 63;
+            for (int q = tid >> 6; q < nq; q += BIN_THREADS / 64) {
+                const int hi = longhi[q];
+                const X xv = longx[q];
+                for (int idx = longlo[q] + lane; idx < hi; idx += 64) xs[idx] = xv;
+            }
+        }
+        lds_barrier();
+        BIN_TICK(2);
+        int rank[BIN_ITEMS]; Z pv[BIN_ITEMS];
+#pragma unroll
+        for (int it = 0; it < BIN_ITEMS; it++) {
+            rank[it] = 0; pv[it] = Z();
+            if (it * BIN_THREADS + tid < ntile) {
+                rank[it] = atomicAdd(&lstart[col[it] >> shift], 1);
+                pv[it] = sr.mult(av[it], xs[it * BIN_THREADS + tid], 0, 0, j);
+            }
+        }
+        lds_barrier();
+        BIN_TICK(3);
+        block_scan_lds<BIN_THREADS>(lstart, nb, wsum);
+        BIN_TICK(4);
+#pragma unroll
+        for (int u = 0; u < NGB; u++) {
+            const int b = u * BIN_THREADS + tid;
+            if (b < nb) delta[b] = gb[u] - lstart[b];
+        }
+#pragma unroll
+        for (int it = 0; it < BIN_ITEMS; it++)
+            if (it * BIN_THREADS + tid < ntile) { const int q = lstart[col[it] >> shift] + rank[it]; scol[q] = col[it]; sval[q] = pv[it]; }
+        lds_barrier();
+        BIN_TICK(5);
+        for (int q = tid; q < ntile; q += BIN_THREADS) {
+            const int c = scol[q];
+            const int64_t dst = (int64_t)delta[c >> shift] + q;
+            pair_idx[dst] = (uint16_t)(c & low);
+            pair_val[dst] = sval[q];
+        }
+        BIN_TICK(6);
+        if (!more) break;
+        lds_barrier();                                        // the next tile reuses every LDS array
+        tile += G; walk++; r0 = nr0;
+        a0_first = na0_first; a1_first = na1_first; x_first = nx_first;
+#pragma unroll
+        for (int it = 0; it < BIN_ITEMS; it++) { col[it] = ncol[it]; av[it] = nav[it]; }
     }
 }
 
@@ -599,20 +745,23 @@ bin_chunks_kernel(int nb, int64_t nwg, const int64_t *__restrict__ table, int *_
         v[b] = (int)((cnt + BIN_CHUNK - 1) / BIN_CHUNK);
     }
     __syncthreads();
-    const int total = block_scan_lds(v, nb, wsum);
+    const int total = block_scan_lds<256>(v, nb, wsum);
     for (int b = threadIdx.x; b < nb; b += 256) chunk_base[b] = v[b];
     if (threadIdx.x == 0) chunk_base[nb] = total;
 }
 
 template <class S>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(BIN_REDUCE_THREADS)
 bin_reduce_kernel(S sr, int shift, int nb, int64_t nwg, const int64_t *__restrict__ table,
                   const int *__restrict__ chunk_base, const uint16_t *__restrict__ pair_idx,
                   const typename S::z_t *__restrict__ pair_val, typename S::z_t *__restrict__ Cx, int64_t cvlen,
                   typename S::z_t *__restrict__ parked) {
-    using Z = typename S::z_t;
-    extern __shared__ __align__(8) unsigned char bin_panel[];
-    Z *panel = reinterpret_cast<Z *>(bin_panel);
+    using Z = typename S::z_t; using P = typename bin_panel<Z>::type;
+    extern __shared__ __align__(8) unsigned char bin_panel_lds[];
+    P *panel = reinterpret_cast<P *>(bin_panel_lds);
+    const int add_code = sr.add_code();
+    auto fold = [&](P *p, Z v) { atomic_monoid<P>(add_code, p, (P)v); };
+    constexpr int NT = BIN_REDUCE_THREADS;
     const int w = blockIdx.x, tid = threadIdx.x;
     if (w >= chunk_base[nb]) return;                          // uniform
     int lo = 0, hi = nb - 1;                                  // the bin of chunk w: largest b with chunk_base[b] <= w
@@ -622,26 +771,48 @@ bin_reduce_kernel(S sr, int shift, int nb, int64_t nwg, const int64_t *__restric
     const int64_t bend = table[(int64_t)(b + 1) * nwg];
     const int64_t e = (s + BIN_CHUNK < bend) ? s + BIN_CHUNK : bend;
     const int width = 1 << shift;
-    const Z id = sr.identity();
-    for (int c = tid; c < width; c += 256) panel[c] = id;
+    const P id = (P)sr.identity();
+    for (int c = tid; c < width; c += NT) panel[c] = id;
     __syncthreads();
-    int64_t q = s + tid;
-    for (; q + 3 * 256 < e; q += 4 * 256) {                   // four pairs in flight per thread
-        const uint16_t c0 = pair_idx[q], c1 = pair_idx[q + 256], c2 = pair_idx[q + 512], c3 = pair_idx[q + 768];
-        const Z v0 = pair_val[q], v1 = pair_val[q + 256], v2 = pair_val[q + 512], v3 = pair_val[q + 768];
-        sr.atomic(&panel[c0], v0); sr.atomic(&panel[c1], v1); sr.atomic(&panel[c2], v2); sr.atomic(&panel[c3], v3);
+    // pairs in groups of eight at aligned positions (one 16-byte load of indices, wide loads of values),
+    // two groups in flight per thread; the ragged ends of the chunk one pair at a time
+    const int64_t s8 = (s + 7) & ~(int64_t)7, e8 = e & ~(int64_t)7;
+    if (s8 < e8) {
+        for (int64_t q = s + tid; q < s8; q += NT) fold(&panel[pair_idx[q]], pair_val[q]);
+        for (int64_t q = e8 + tid; q < e; q += NT) fold(&panel[pair_idx[q]], pair_val[q]);
+        struct alignas(16) Idx8 { uint16_t c[8]; };
+        struct alignas(16) Val8 { Z v[8]; };
+        const Idx8 *gi = reinterpret_cast<const Idx8 *>(pair_idx);
+        const Val8 *gv = reinterpret_cast<const Val8 *>(pair_val);
+        const int64_t g0 = s8 >> 3, g1 = e8 >> 3;
+        int64_t g = g0 + tid;
+        for (; g + NT < g1; g += 2 * NT) {
+            const Idx8 ia = gi[g], ib = gi[g + NT];
+            const Val8 va = gv[g], vb = gv[g + NT];
+#pragma unroll
+            for (int u = 0; u < 8; u++) fold(&panel[ia.c[u]], va.v[u]);
+#pragma unroll
+            for (int u = 0; u < 8; u++) fold(&panel[ib.c[u]], vb.v[u]);
+        }
+        for (; g < g1; g += NT) {
+            const Idx8 ia = gi[g];
+            const Val8 va = gv[g];
+#pragma unroll
+            for (int u = 0; u < 8; u++) fold(&panel[ia.c[u]], va.v[u]);
+        }
+    } else {
+        for (int64_t q = s + tid; q < e; q += NT) fold(&panel[pair_idx[q]], pair_val[q]);
     }
-    for (; q < e; q += 256) sr.atomic(&panel[pair_idx[q]], pair_val[q]);
     __syncthreads();
     if (nch == 1) {
         const int64_t base = (int64_t)b << shift;
-        for (int c = tid; c < width; c += 256) {
-            const Z v = panel[c];
-            if (base + c < cvlen && !bits_equal<Z>(v, id)) Cx[base + c] = sr.add(Cx[base + c], v);
+        for (int c = tid; c < width; c += NT) {
+            const P v = panel[c];
+            if (base + c < cvlen && !bits_equal<P>(v, id)) Cx[base + c] = sr.add(Cx[base + c], (Z)v);
         }
     } else {
         Z *out = parked + (int64_t)w * width;
-        for (int c = tid; c < width; c += 256) out[c] = panel[c];
+        for (int c = tid; c < width; c += NT) out[c] = (Z)panel[c];
     }
 }
 
@@ -659,7 +830,15 @@ bin_combine_kernel(S sr, int shift, int64_t cvlen, const int *__restrict__ chunk
         if (nch <= 1) continue;
         const Z *src = parked + (int64_t)first * width + (i & (width - 1));
         Z acc = src[0];
-        for (int ch = 1; ch < nch; ch++) acc = sr.add(acc, src[(int64_t)ch * width]);
+        int ch = 1;
+        for (; ch + 8 <= nch; ch += 8) {                      // eight loads in flight
+            Z t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = src[(int64_t)(ch + u) * width];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = sr.add(acc, t[u]);
+        }
+        for (; ch < nch; ch++) acc = sr.add(acc, src[(int64_t)ch * width]);
         Cx[i] = sr.add(Cx[i], acc);
     }
 }
@@ -670,7 +849,7 @@ static gba_info saxpy4_binned(S sr, const gba_matrix *A, const DenseView &Bv, in
                               typename S::z_t *cx, hipStream_t st, bool *done) {
     using Z = typename S::z_t;
     *done = false;
-    constexpr int shift = bin_shift<Z>::v;
+    constexpr int shift = bin_shift<Z>::v, ITEMS = bin_items<S>::v, BIN_TILE = BIN_THREADS * ITEMS;
     const int64_t nnz = A->nvals, nb64 = ceil_div(cvlen, (int64_t)1 << shift);
     if (Bv.b || nnz < ((int64_t)1 << 20) || nnz >= ((int64_t)1 << 31) || cvlen >= ((int64_t)1 << 31) ||
         nb64 > BIN_MAX || cvdim > 8) return GBA_SUCCESS;
@@ -684,18 +863,28 @@ static gba_info saxpy4_binned(S sr, const gba_matrix *A, const DenseView &Bv, in
     GBA_OK(pidx.alloc((size_t)nnz * 2));
     GBA_OK(pval.alloc((size_t)nnz * sizeof(Z)));
     GBA_OK(parked.alloc((size_t)maxchunks * sizeof(Z) << shift));
-    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)nwg), dim3(BIN_THREADS), (size_t)nb * 4, st, A->nvec, A->p, A->i,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_count_kernel<ITEMS>), dim3((unsigned)ceil_div(nwg, BIN_COUNT_TILES)), dim3(BIN_THREADS),
+                       (size_t)nb * 4 * BIN_COUNT_TILES, st, A->nvec, A->p, A->i,
                        shift, nb, nwg, table.as<int64_t>());
     GBA_OK(dev_cumsum_i64(table.as<int64_t>(), ncell, st));
     int64_t rb = ceil_div(A->nvec, 256); if (rb > 8192) rb = 8192; if (rb < 1) rb = 1;
     hipLaunchKernelGGL(dot_tile_rows_kernel, dim3((unsigned)rb), dim3(256), 0, st, A->nvec, A->p, (int64_t)BIN_TILE,
                        tile_rows.as<int64_t>());
     hipLaunchKernelGGL(bin_chunks_kernel, dim3(1), dim3(256), 0, st, nb, nwg, table.as<int64_t>(), chunk_base.as<int>());
+    // as many bin_scatter workgroups as stay resident together, each walking tiles (at most BIN_WALK of them)
+    int per_cu = 1;
+    GBA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bin_scatter_kernel<S, ITEMS>, BIN_THREADS, (size_t)nb * 8));
+    int64_t sgrid = (int64_t)ctx().num_cu * (per_cu > 0 ? per_cu : 1);
+    sgrid = (sgrid + 7) & ~(int64_t)7;                        // a multiple of the eight XCDs
+    const int64_t need = 8 * ceil_div(ceil_div(nwg, 8), BIN_WALK);    // no workgroup walks more than BIN_WALK tiles
+    if (sgrid < need) sgrid = need;
     for (int64_t j = 0; j < cvdim; j++) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_scatter_kernel<S>), dim3((unsigned)nwg), dim3(BIN_THREADS), (size_t)nb * 8, st,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_scatter_kernel<S, ITEMS>), dim3((unsigned)sgrid), dim3(BIN_THREADS), (size_t)nb * 8, st,
                            sr, A->nvec, A->p, A->i, A->x, A->iso, Bv, j, tile_rows.as<int64_t>(), shift, nb, nwg,
                            table.as<int64_t>(), pidx.as<uint16_t>(), pval.as<Z>());
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_reduce_kernel<S>), dim3((unsigned)maxchunks), dim3(256), sizeof(Z) << shift, st,
+        GBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_reduce_kernel<S>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(typename bin_panel<Z>::type) << shift)));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_reduce_kernel<S>), dim3((unsigned)maxchunks), dim3(BIN_REDUCE_THREADS), sizeof(typename bin_panel<Z>::type) << shift, st,
                            sr, shift, nb, nwg, table.as<int64_t>(), chunk_base.as<int>(), pidx.as<uint16_t>(), pval.as<Z>(),
                            cx + j * cvlen, cvlen, parked.as<Z>());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_combine_kernel<S>), dim3(grid_for(cvlen)), dim3(256), 0, st, sr, shift, cvlen,
@@ -703,6 +892,16 @@ static gba_info saxpy4_binned(S sr, const gba_matrix *A, const DenseView &Bv, in
     }
     GBA_HIP(hipGetLastError());
     GBA_HIP(hipStreamSynchronize(st));                        // the buffers above go back to the pool on return
+#ifdef GBA_PANEL_TICKS
+    if (getenv("GBA_PANEL_PROF")) {
+        unsigned long long t[16], z[16] = {0};
+        GBA_HIP(hipMemcpyFromSymbol(t, HIP_SYMBOL(bin_ticks), sizeof(t)));
+        GBA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bin_ticks), z, sizeof(z)));
+        fprintf(stderr, "bin_scatter ticks/tile: loads %.0f fill %.0f longfill %.0f rank %.0f scan %.0f sort %.0f write %.0f (tiles %ld)\n",
+                (double)t[0] / nwg, (double)t[1] / nwg, (double)t[2] / nwg, (double)t[3] / nwg, (double)t[4] / nwg,
+                (double)t[5] / nwg, (double)t[6] / nwg, (long)nwg);
+    }
+#endif
     *done = true;
     return GBA_SUCCESS;
 }

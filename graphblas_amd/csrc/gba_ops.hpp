@@ -339,6 +339,7 @@ struct Srt {
     __device__ ZT add(ZT x, ZT y) const { return add_tt<ZT>(add_op, x, y); }
     __host__ __device__ ZT identity() const { return identity_tt<ZT>(add_op); }
     __device__ void atomic(acc_t *p, ZT t) const { atomic_monoid<ZT>(add_op, p, t); }
+    __host__ __device__ int add_code() const { return add_op; }
     __host__ __device__ bool add_is_any() const { return add_op == GBA_ANY; }
 };
 
@@ -358,6 +359,7 @@ struct Sct {
     __device__ ZT add(ZT x, ZT y) const { return add_tt<ZT>(ADD, x, y); }
     __host__ __device__ ZT identity() const { return identity_tt<ZT>(ADD); }
     __device__ void atomic(acc_t *p, ZT t) const { atomic_monoid<ZT>(ADD, p, t); }
+    __host__ __device__ int add_code() const { return ADD; }
     __host__ __device__ bool add_is_any() const { return ADD == GBA_ANY; }
 };
 

@@ -1,5 +1,5 @@
 // Micro-benchmark (gfx950): what one CU sustains for the LDS operations of the panel kernels, 16 waves per CU,
-// pseudo-random addresses: ds_or_b32, ds_add_f64, ds_read_b64, ds_add_u32 with return, and for random 256-byte
+// pseudo-random addresses: ds_or_b32, ds_add_f64, ds_add_f32, ds_read_b64, ds_add_u32 with and without return, and for random 256-byte
 // chunk reads of a large array by depth of the per-wave ring.  Prints wave-instructions per microsecond per CU.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -13,6 +13,7 @@ __global__ void __launch_bounds__(1024) lds_kernel(int iters, uint32_t span, dou
     uint32_t *w32 = reinterpret_cast<uint32_t *>(smem);
     double *w64 = reinterpret_cast<double *>(smem);
     uint2 *wp = reinterpret_cast<uint2 *>(smem);
+    float *wf = reinterpret_cast<float *>(smem);
     for (uint32_t q = threadIdx.x; q < span * 2; q += 1024) w32[q] = 0;
     __syncthreads();
     uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
@@ -29,6 +30,9 @@ __global__ void __launch_bounds__(1024) lds_kernel(int iters, uint32_t span, dou
             if (OP == 4) w64[a] = 1.0;
             if (OP == 5) atomicAdd(&w64[(a & ~63u) + (threadIdx.x & 63)], 1.0);      // conflict-free fp64 adds
             if (OP == 6) atomicOr(&w32[2 * ((a & ~63u) + (threadIdx.x & 63))], 1u << (x & 31));
+            if (OP == 7) atomicAdd(&wf[a], 1.0f);
+            if (OP == 8) atomicAdd(&wf[(a & ~63u) + (threadIdx.x & 63)], 1.0f);
+            if (OP == 9) atomicAdd(&w32[a], 1u);
         }
     }
     if (acc == 123.456) sink[0] = acc;
@@ -73,9 +77,10 @@ int main() {
     double *sink; CK(hipMalloc(&sink, 8));
     const int ncu = 256, iters = 2000;
     const char *names[] = {"ds_or_b32 random", "ds_add_f64 random", "ds_read_b64 random", "ds_add_rtn_u32 random", "ds_write_b64 random",
-                           "ds_add_f64 conflict-free", "ds_or_b32 conflict-free"};
+                           "ds_add_f64 conflict-free", "ds_or_b32 conflict-free", "ds_add_f32 random", "ds_add_f32 conflict-free",
+                           "ds_add_u32 random"};
     for (uint32_t span : {6144u, 1024u}) {
-        double ms[7];
+        double ms[10];
         ms[0] = time_kernel(lds_kernel<0>, dim3(ncu), dim3(1024), 65536, iters, span, sink);
         ms[1] = time_kernel(lds_kernel<1>, dim3(ncu), dim3(1024), 65536, iters, span, sink);
         ms[2] = time_kernel(lds_kernel<2>, dim3(ncu), dim3(1024), 65536, iters, span, sink);
@@ -83,7 +88,10 @@ int main() {
         ms[4] = time_kernel(lds_kernel<4>, dim3(ncu), dim3(1024), 65536, iters, span, sink);
         ms[5] = time_kernel(lds_kernel<5>, dim3(ncu), dim3(1024), 65536, iters, span, sink);
         ms[6] = time_kernel(lds_kernel<6>, dim3(ncu), dim3(1024), 65536, iters, span, sink);
-        for (int o = 0; o < 7; o++) {
+        ms[7] = time_kernel(lds_kernel<7>, dim3(ncu), dim3(1024), 65536, iters, span, sink);
+        ms[8] = time_kernel(lds_kernel<8>, dim3(ncu), dim3(1024), 65536, iters, span, sink);
+        ms[9] = time_kernel(lds_kernel<9>, dim3(ncu), dim3(1024), 65536, iters, span, sink);
+        for (int o = 0; o < 10; o++) {
             const double winst = 16.0 * iters * 8;                       // wave-instructions per CU
             printf("span %5u %-26s %8.3f ms  %7.1f wave-instr/us/CU  %6.1f ns per wave-instr\n", span, names[o], ms[o],
                    winst / (ms[o] * 1e3), ms[o] * 1e6 / winst);
