@@ -7,7 +7,10 @@
  * Parity pin: this restatement is checked against the reference's own
  * known-answer material for this path (Demo/Output/gauss_demo.out:223-405 --
  * saxbit, dot3, colscale, rowscale, dot4, saxpy4, saxpy5 on a user-defined type
- * -- replayed by oracle/gauss_replay.c, and Demo/Output/wildtype_demo.out).
+ * -- replayed by oracle/gauss_replay.c; Demo/Output/wildtype_demo.out:142-330 --
+ * saxpy3 and dot3 on a 192-byte user-defined type -- replayed by
+ * oracle/wildtype_replay.c; tests/test_oracle.py compares both with fixtures
+ * transcribed from those files).
  * The reference library itself cannot be built in this environment: its
  * sources need GB_config.h and GB_JITpackage.c, which only its cmake build
  * generates.
@@ -27,6 +30,8 @@
 #endif
 #include "../include/graphblas_amd.h"
 #include "grb_oracle.h"
+
+#define ORC_MAX_VALUE 256            /* bytes of the largest value the scratch buffers hold (user-defined types) */
 
 /* ------------------------------------------------------------ operators -- */
 /* z = f(x,y) on raw bytes, generated for every built-in type.  Integer
@@ -208,6 +213,7 @@ int orc_semiring_builtin(orc_semiring *s, const gba_semiring *in, bool flipxy) {
 
 void orc_semiring_user(orc_semiring *s, orc_binfn fadd, orc_binfn fmult, size_t xsize, size_t ysize, size_t zsize) {
     memset(s, 0, sizeof(*s));
+    if (xsize > ORC_MAX_VALUE || ysize > ORC_MAX_VALUE || zsize > ORC_MAX_VALUE) { fprintf(stderr, "oracle: user type larger than %d bytes\n", ORC_MAX_VALUE); abort(); }
     s->fadd = fadd; s->fmult = fmult; s->xsize = xsize; s->ysize = ysize; s->zsize = zsize;
     s->xtype = s->ytype = s->ztype = GBA_UDT; s->add_op = GBA_USER_BINOP; s->mult_op = GBA_USER_BINOP;
 }
@@ -228,7 +234,7 @@ static inline void sr_mult(const orc_semiring *s, void *t, const void *a, const 
     s->fmult(t, a, b);
 }
 
-static const uint8_t ZEROS[32] = {0};
+static const uint8_t ZEROS[ORC_MAX_VALUE] = {0};
 static inline const void *valp(const void *x, int64_t p, size_t size, bool iso, bool pattern) {
     if (pattern || !x) return ZEROS;
     return (const uint8_t *)x + (iso ? 0 : p) * size;
@@ -379,7 +385,7 @@ int orc_saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_str
                         if (hf[i] != mark) { hf[i] = mark; ((double *)hx)[i] = tt; hl[cjnz++] = i; }
                         else ((double *)hx)[i] += tt;
                     } else {
-                        uint8_t tt[32];
+                        uint8_t tt[ORC_MAX_VALUE];
                         sr_mult(s, tt, valp(A->x, pA, s->xsize, A->iso, s->a_pattern), bkj, i, k, j);
                         if (hf[i] != mark) { hf[i] = mark; memcpy(hx + i * zs, tt, zs); hl[cjnz++] = i; }
                         else s->fadd(hx + i * zs, hx + i * zs, tt);
@@ -423,7 +429,7 @@ static bool dot_ss(const orc_semiring *s, const gba_matrix *A, const gba_matrix 
     int64_t pA = A->p[i], pA_end = A->p[i + 1], pB = B->p[j], pB_end = B->p[j + 1];
     const int64_t ainz = pA_end - pA, bjnz = pB_end - pB;
     bool found = false;
-    uint8_t t[32];
+    uint8_t t[ORC_MAX_VALUE];
     if (ainz == 0 || bjnz == 0) return false;
     if (A->i[pA_end - 1] < B->i[pB] || B->i[pB_end - 1] < A->i[pA]) return false;
     while (pA < pA_end && pB < pB_end) {
@@ -444,7 +450,7 @@ static bool dot_any(const orc_semiring *s, const gba_matrix *A, const gba_matrix
     const bool As = A->sparsity == GBA_SPARSE, Bs = B->sparsity == GBA_SPARSE;
     if (As && Bs) return dot_ss(s, A, B, i, j, cij);
     bool found = false;
-    uint8_t t[32];
+    uint8_t t[ORC_MAX_VALUE];
     const int64_t vlen = A->vlen;
     #define TERM(k, pa, pb) do { \
         sr_mult(s, t, valp(A->x, (pa), s->xsize, A->iso, s->a_pattern), valp(B->x, (pb), s->ysize, B->iso, s->b_pattern), i, (k), j); \
@@ -549,7 +555,7 @@ int orc_dot4(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const orc_
     #pragma omp parallel for schedule(dynamic, 16)
     for (int64_t j = 0; j < C->vdim; j++)
         for (int64_t i = 0; i < cvlen; i++) {
-            uint8_t cij[32];
+            uint8_t cij[ORC_MAX_VALUE];
             if (dot_any(s, A, B, i, j, cij)) {
                 uint8_t *c = (uint8_t *)C->x + (j * cvlen + i) * zs;
                 s->fadd(c, c, cij);
@@ -573,7 +579,7 @@ int orc_saxpy4(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const or
             const void *bkj = valp(B->x, pB, s->ysize, B->iso, s->b_pattern);
             for (int64_t pA = A->p[k]; pA < A->p[k + 1]; pA++) {
                 const int64_t i = A->i[pA];
-                uint8_t t[32];
+                uint8_t t[ORC_MAX_VALUE];
                 sr_mult(s, t, valp(A->x, pA, s->xsize, A->iso, s->a_pattern), bkj, i, k, j);
                 uint8_t *c = (uint8_t *)C->x + (j * C->vlen + i) * zs;
                 s->fadd(c, c, t);
@@ -596,7 +602,7 @@ int orc_saxpy5(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const or
             for (int64_t i = 0; i < A->vlen; i++) {
                 const int64_t pA = k * A->vlen + i;
                 if (A->sparsity == GBA_BITMAP && !A->b[pA]) continue;
-                uint8_t t[32];
+                uint8_t t[ORC_MAX_VALUE];
                 sr_mult(s, t, valp(A->x, pA, s->xsize, A->iso, s->a_pattern), bkj, i, k, j);
                 uint8_t *c = (uint8_t *)C->x + (j * C->vlen + i) * zs;
                 s->fadd(c, c, t);
@@ -632,7 +638,7 @@ int orc_saxbit(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_str
                 if (A->sparsity == GBA_SPARSE) { pA = q; i = A->i[q]; }
                 else { i = q; pA = k * cvlen + i; if (A->sparsity == GBA_BITMAP && !A->b[pA]) continue; }
                 if (M && ((hm[i] != 0) == Mask_comp)) continue;
-                uint8_t t[32];
+                uint8_t t[ORC_MAX_VALUE];
                 sr_mult(s, t, valp(A->x, pA, s->xsize, A->iso, s->a_pattern), bkj, i, k, j);
                 uint8_t *c = Cx + (j * cvlen + i) * zs;
                 if (Cb[j * cvlen + i]) s->fadd(c, c, t);
@@ -734,7 +740,7 @@ int orc_mxm_spec(int8_t *present, void *value, int64_t nrows, int64_t ncols, int
     for (int64_t r = 0; r < nrows; r++)
         for (int64_t c = 0; c < ncols; c++) {
             /* T(r,c) = sum_k A(r,k)*B(k,c), terms in increasing k */
-            uint8_t t[32], tk[32], ca[32], cb[32]; bool t_in = false;
+            uint8_t t[ORC_MAX_VALUE], tk[ORC_MAX_VALUE], ca[ORC_MAX_VALUE], cb[ORC_MAX_VALUE]; bool t_in = false;
             for (int64_t k = 0; k < inner; k++) {
                 const void *a, *b;
                 if (!get_entry(A, A_tran ? k : r, A_tran ? r : k, &a, orc_type_size(A->type))) continue;
@@ -757,7 +763,7 @@ int orc_mxm_spec(int8_t *present, void *value, int64_t nrows, int64_t ncols, int
                 else s.fmult(tk, a, b);
                 if (t_in) s.fadd(t, t, tk); else { memcpy(t, tk, s.zsize); t_in = true; }
             }
-            if (t_in && cast_t) { uint8_t tc[32]; orc_cast(tc, C->type, t, s.ztype); memcpy(t, tc, zs); }
+            if (t_in && cast_t) { uint8_t tc[ORC_MAX_VALUE]; orc_cast(tc, C->type, t, s.ztype); memcpy(t, tc, zs); }
             /* Z = accum (C,T); C<M,replace> = Z */
             const void *cv; const bool c_in = get_entry(C, r, c, &cv, zs);
             bool m = true;
@@ -767,7 +773,7 @@ int orc_mxm_spec(int8_t *present, void *value, int64_t nrows, int64_t ncols, int
                 if (m && !Mask_struct) { bool nz = false; for (size_t q = 0; q < ms; q++) nz |= (((const uint8_t *)mv)[q] != 0); m = nz; }
             }
             if (Mask_comp) m = !m;
-            uint8_t z[32]; bool z_in;
+            uint8_t z[ORC_MAX_VALUE]; bool z_in;
             if (facc) {
                 if (c_in && t_in) { facc(z, cv, t); z_in = true; }
                 else if (c_in) { memcpy(z, cv, zs); z_in = true; }

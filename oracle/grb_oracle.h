@@ -54,6 +54,7 @@ int orc_matrix_wait(gba_matrix *C);
 /* replay of the GrB_mxm sequence of Demo/Program/gauss_demo.c:377-471 with the
  * oracle's methods; prints the matrices in the demo's own format */
 int orc_gauss_replay(char *out, size_t out_size);
+int orc_wildtype_replay(char *out, size_t out_size);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ def dll():
         d.orc_matrix_wait.argtypes = [M]
         d.orc_matrix_free_content.argtypes = [M]
         d.orc_gauss_replay.argtypes = [C.c_char_p, C.c_size_t]
+        d.orc_wildtype_replay.argtypes = [C.c_char_p, C.c_size_t]
         d.orc_num_threads.restype = C.c_int
         _dll = d
     return _dll
@@ -178,6 +179,12 @@ def cast(values, from_type, to_type):
 def gauss_replay():
     buf = C.create_string_buffer(1 << 16)
     _chk(dll().orc_gauss_replay(buf, len(buf)), "gauss_replay")
+    return buf.value.decode()
+
+
+def wildtype_replay():
+    buf = C.create_string_buffer(1 << 16)
+    _chk(dll().orc_wildtype_replay(buf, len(buf)), "wildtype_replay")
     return buf.value.decode()
 
 

@@ -1,0 +1,148 @@
+"""The configurations the path is quoted on, at full size, checked through properties that do not need a full
+CPU replay: SpMV at RMAT-22 against a double-precision product with a stated bound, the triangle count of
+RMAT-20 against the oracle's total and scipy on sampled rows, BFS at RMAT-22 level by level, and SSSP
+(Bellman-Ford over MIN_PLUS_FP64) at RMAT-20 bit for bit against the same iteration in numpy."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.csgraph as csgraph
+
+import graphblas_amd as g
+from graphblas_amd import Matrix, Type, gen
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _free(*ds):
+    for d in ds:
+        d.free()
+
+
+def test_spmv_rmat22_fp32_both_forms_within_the_rounding_bound(gba):
+    """y = A*x (dot4, gather) and y' = x'*A (saxpy4 through destination bins) with PLUS_TIMES_FP32 at RMAT-22.
+    Reference: the same fp32 inputs multiplied in fp64.  Bound per entry: a sum of m positive fp32 products in
+    any order is within (m + 1) * 2^-24 * sum|a*x| of the exact sum (one rounding per product, at most m - 1 per
+    addition chain); the values are positive, so sum|a*x| is the reference itself."""
+    A = gen.rmat(22, 16, seed=42, type=Type.FP32)                       # CSR
+    n = A.nrows
+    x = (np.random.default_rng(1).random(n) + 0.5).astype(np.float32)
+    S = A.to_scipy().astype(np.float64)
+    dA, dx = A.to_device(), Matrix.full_vector(x).to_device()
+    eps = 2.0 ** -24
+    for form in ("mxv", "vxm"):
+        dy = Matrix.full_vector(np.zeros(n, np.float32)).to_device()
+        if form == "mxv":
+            rep = g.mxv(dy, None, "PLUS_FP32", "PLUS_TIMES_FP32", dA, dx)
+            ref, terms = S @ x.astype(np.float64), np.diff(S.indptr)
+        else:
+            rep = g.vxm(dy, None, "PLUS_FP32", "PLUS_TIMES_FP32", dx, dA)
+            ref, terms = S.T @ x.astype(np.float64), np.bincount(S.indices, minlength=n)
+        assert g.Method.NAMES[rep.method] == ("dot4" if form == "mxv" else "saxpy4")
+        y = dy.to_host().x.astype(np.float64)
+        bound = (terms + 1) * eps * ref + 1e-30
+        worst = float(np.max(np.abs(y - ref) / bound))
+        assert worst <= 1.0, (form, worst)
+        assert np.array_equal(y == 0, ref == 0), form                    # empty rows / columns stay untouched
+        dy.free()
+    _free(dA, dx)
+
+
+def test_triangle_count_rmat20_exact(gba):
+    """C<L,struct> = L*L' with PLUS_PAIR_INT64 (dot3): the total equals the oracle's, and every C(i,j) of 256
+    sampled rows equals scipy's integer product (L[i,:] * L') .* L[i,:]."""
+    A = gen.rmat(20, 16, seed=42, type=Type.INT64, values="ones", symmetric=True, drop_diagonal=True)
+    L = gen.tril_strict(A)
+    n = L.nrows
+    dL = L.to_device()
+    C = g.DeviceMatrix.empty(n, n, Type.INT64)
+    rep = g.mxm(C, dL, None, "PLUS_PAIR_INT64", dL, dL, g.descriptor("ST1"))
+    assert g.Method.NAMES[rep.method] == "dot3"
+    Ch = C.to_host()
+    live = Ch.i >= 0
+    want = oracle.dot3(L, True, L, L, "PLUS_PAIR_INT64")
+    wlive = want.i >= 0
+    assert int(Ch.x[live].sum()) == int(want.x[wlive].sum())
+    assert np.array_equal(Ch.p, want.p) and np.array_equal(Ch.i, want.i)
+    assert np.array_equal(Ch.x[live], want.x[wlive])
+    S = L.to_scipy().astype(np.int64); S.data[:] = 1
+    rows = np.arange(0, n, 4096)
+    R = S[rows]
+    ref = (R @ S.T.tocsr()).multiply(R).tocsr()
+    ref.sort_indices()
+    for q, i in enumerate(rows):
+        seg = slice(Ch.p[i], Ch.p[i + 1])
+        keep = Ch.i[seg] >= 0
+        assert np.array_equal(Ch.i[seg][keep], ref.indices[ref.indptr[q]:ref.indptr[q + 1]]), i
+        assert np.array_equal(Ch.x[seg][keep], ref.data[ref.indptr[q]:ref.indptr[q + 1]]), i
+    _free(dL, C)
+
+
+def test_bfs_rmat22_levels_and_parents(gba):
+    """Level-synchronous BFS, q<!pi,struct,replace> = q'*A with ANY_SECONDI_INT64 per level: the set found at
+    every level is exactly the set at that distance (scipy), and every parent is a frontier vertex of the level
+    before with an edge to its child.  (Which parent ANY picks is free; the reference makes no promise either.)"""
+    A = gen.rmat(22, 16, seed=42, type=Type.INT64, values="ones", symmetric=True, drop_diagonal=True)
+    n = A.nrows
+    S = A.to_scipy()
+    src = int(np.argmax(np.diff(A.p)))
+    dist = csgraph.shortest_path(S, method="D", unweighted=True, indices=src)
+    dA = A.to_device()
+    pi_b = np.zeros(n, np.int8); pi_x = np.zeros(n, np.int64)
+    pi_b[src] = 1; pi_x[src] = src
+    q = Matrix.sparse_vector(n, [src], np.array([src], np.int64))
+    keys = None
+    for level in range(64):
+        dq = q.to_device()
+        dpi = Matrix.bitmap_vector(pi_x, pi_b).to_device()
+        dw = Matrix.sparse_vector(n, [], np.zeros(0, np.int64)).to_device()
+        g.vxm(dw, dpi, None, "ANY_SECONDI_INT64", dq, dA, "RSC")
+        r, _, parents = dw.to_host().coo()
+        _free(dq, dpi, dw)
+        want = np.flatnonzero(dist == level + 1)
+        assert np.array_equal(np.sort(r), want), level
+        if len(r) == 0:
+            break
+        order = np.argsort(r)
+        r, parents = r[order], parents[order]
+        assert np.all(dist[parents] == level), level
+        # the edge parent -> child exists (about 2000 children per level): the child is in the parent's sorted row
+        for k in range(0, len(r), max(len(r) // 2000, 1)):
+            row = A.i[A.p[parents[k]]:A.p[parents[k] + 1]]
+            j = int(np.searchsorted(row, r[k]))
+            assert j < len(row) and row[j] == r[k], (level, int(parents[k]), int(r[k]))
+        pi_b[r] = 1; pi_x[r] = parents
+        if len(r) > n // 8:
+            b = np.zeros(n, np.int8); x = np.zeros(n, np.int64); b[r] = 1; x[r] = parents
+            q = Matrix.bitmap_vector(x, b)
+        else:
+            q = Matrix.sparse_vector(n, r, parents)
+    assert int(pi_b.sum()) == int(np.isfinite(dist).sum())
+    dA.free()
+
+
+def test_sssp_rmat20_bellman_ford_bit_exact(gba):
+    """d = min(d, d min.+ A) until it stops changing, MIN_PLUS_FP64 through gba_vxm with the MIN accumulator
+    (saxpy4, in place).  Every candidate is one fp64 addition of the same two numbers on both sides and MIN is
+    exact, so the distances agree bit for bit with the same synchronous iteration in numpy."""
+    A = gen.rmat(20, 16, seed=42, type=Type.FP64)                       # CSR, weights uniform in (0, 1]
+    n = A.nrows
+    rows = np.repeat(np.arange(n), np.diff(A.p))
+    src = int(np.argmax(np.diff(A.p)))
+    d = np.full(n, np.inf); d[src] = 0.0
+    dA = A.to_device()
+    for it in range(64):
+        dcur = Matrix.full_vector(d).to_device()
+        dnew = Matrix.full_vector(d.copy()).to_device()
+        rep = g.vxm(dnew, None, "MIN_FP64", "MIN_PLUS_FP64", dcur, dA)
+        assert g.Method.NAMES[rep.method] == "saxpy4"
+        got = dnew.to_host().x
+        _free(dcur, dnew)
+        want = d.copy()
+        np.minimum.at(want, A.i, d[rows] + A.x)
+        assert np.array_equal(got, want), it
+        if np.array_equal(want, d):
+            break
+        d = want
+    assert it > 2 and np.isfinite(d).sum() > n // 4
+    dA.free()

@@ -110,3 +110,83 @@ def test_udt_compile_error_is_reported(gba):
     with pytest.raises(g.GrbError):
         g.mxm_udt(dC, None, None, bad, dA, dA)
     dA.free(); dC.free()
+
+
+# ---------------------------------------------------------------- wildtype ----
+# the 192-byte type and the two operators of Demo/Program/wildtype_demo.c:31-46, 112-190, as the strings
+# the application hands to GxB_Type_new / GxB_BinaryOp_new
+WILD_DEFN = "typedef struct { double stuff [4][4] ; char whatstuff [64] ; } wildtype ;"
+WILDADD_DEFN = """void wildadd (wildtype *z, const wildtype *x, const wildtype *y)
+{
+   for (int i = 0 ; i < 4 ; i++)
+   {
+       for (int j = 0 ; j < 4 ; j++)
+       {
+           z->stuff [i][j] = x->stuff [i][j] + y->stuff [i][j] ;
+       }
+   }
+   const char *psrc = "this was added" ;
+   char *pdst = z->whatstuff ;
+   while ((*pdst++ = *psrc++)) ;
+}"""
+WILDMULT_DEFN = """void wildmult (wildtype *z, const wildtype *x, const wildtype *y)
+{
+   for (int i = 0 ; i < 4 ; i++)
+   {
+       for (int j = 0 ; j < 4 ; j++)
+       {
+           z->stuff [i][j] = 0 ;
+           for (int k = 0 ; k < 4 ; k++)
+           {
+               z->stuff [i][j] += (x->stuff [i][k] * y->stuff [k][j]) ;
+           }
+       }
+   }
+   const char *psrc = "this was multiplied" ;
+   char *pdst = z->whatstuff ;
+   while ((*pdst++ = *psrc++)) ;
+}"""
+WILD_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "wildtype_demo_mxm.json")
+
+
+def _wild_matrix(dt, entries, n=10):
+    """entries: the fixture's list of {i, j, text, stuff}; an n-by-n sparse matrix held by row."""
+    es = sorted(entries, key=lambda e: (e["i"], e["j"]))
+    x = np.zeros(len(es), dtype=dt)
+    for q, e in enumerate(es):
+        x[q]["stuff"] = np.array(e["stuff"])
+        x[q]["whatstuff"] = e["text"].encode()
+    p = np.zeros(n + 1, np.int64)
+    np.add.at(p, np.array([e["i"] for e in es], np.int64) + 1, 1)
+    return Matrix(n, n, Type.UDT, Sparsity.SPARSE, False, p=np.cumsum(p), i=np.array([e["j"] for e in es], np.int64), x=x)
+
+
+def _wild_check(M, want):
+    r, c, v = M.coo()
+    got = sorted(zip(r.tolist(), c.tolist(), range(len(r))))
+    assert [(i, j) for i, j, _ in got] == [(e["i"], e["j"]) for e in want["entries"]], want["name"]
+    for (i, j, q), e in zip(got, want["entries"]):
+        assert bytes(v[q]["whatstuff"]).split(b"\0")[0].decode() == e["text"], (want["name"], i, j)
+        flat = [x for row in e["stuff"] for x in row]
+        assert ["%.1f" % x for x in v[q]["stuff"].ravel()] == ["%.1f" % x for x in flat], (want["name"], i, j)
+
+
+def test_wildtype_demo_on_the_device(gba):
+    """Demo/Program/wildtype_demo.c:366 and :381 through gba_mxm_udt: C = A*B, then C<M,struct,replace> = C*C'
+    with C its own operands, against the entries the reference prints (Demo/Output/wildtype_demo.out:142-330).
+    The inputs printed there are exact (integers and halves); results are compared at the printed precision."""
+    want = json.load(open(WILD_GOLDEN))
+    dt = g.register_udt(np.dtype([("stuff", "<f8", (4, 4)), ("whatstuff", "S64")]))
+    assert dt.itemsize == 192
+    sr = g.user_semiring("wildtype", WILD_DEFN, dt.itemsize, "wildadd", WILDADD_DEFN, "wildmult", WILDMULT_DEFN)
+    dA, dB = _wild_matrix(dt, want[0]["entries"]).to_device(), _wild_matrix(dt, want[1]["entries"]).to_device()
+    dC = Matrix.sparse_empty(10, 10, Type.UDT).to_device()
+    g.mxm_udt(dC, None, None, sr, dA, dB)
+    _wild_check(dC.to_host(), want[2])
+    Mk = Matrix(10, 10, Type.BOOL, Sparsity.SPARSE, False, p=np.array([0, 0, 0, 2, 4, 4, 4, 4, 4, 4, 4], np.int64),
+                i=np.array([2, 3, 2, 3], np.int64), x=np.ones(4, bool))
+    dM = Mk.to_device()
+    g.mxm_udt(dC, dM, None, sr, dC, dC, "RST1")
+    _wild_check(dC.to_host(), want[3])
+    for d in (dA, dB, dC, dM):
+        d.free()

@@ -37,6 +37,27 @@ def test_gauss_demo_known_answers():
         assert m in w["burble"]
 
 
+def test_wildtype_demo_known_answers():
+    """The oracle's saxpy3 and dot3 on the 192-byte user-defined type of Demo/Program/wildtype_demo.c reproduce
+    Demo/Output/wildtype_demo.out (fixture tests/golden/wildtype_demo_mxm.json): positions, the text each
+    operator leaves behind, and every number at the precision the reference prints ("%10.1f")."""
+    want = json.load(open(os.path.join(GOLDEN, "wildtype_demo_mxm.json")))
+    blocks = [b for b in re.split(r"^== ", oracle.wildtype_replay(), flags=re.M) if b.strip()]
+    assert len(blocks) == len(want) == 4
+    line = re.compile(r"^\((\d+),(\d+)\) \[(.*?)\] (.*)$")
+    for blk, w in zip(blocks, want):
+        lines = blk.strip().splitlines()
+        assert lines[0] == w["name"]
+        assert len(lines) - 1 == len(w["entries"])
+        for got, e in zip(lines[1:], w["entries"]):
+            m = line.match(got)
+            assert (int(m.group(1)), int(m.group(2)), m.group(3)) == (e["i"], e["j"], e["text"]), w["name"]
+            vals = [float(v) for v in m.group(4).split()]
+            flat = [v for row in e["stuff"] for v in row]
+            assert ["%.1f" % v for v in vals] == ["%.1f" % v for v in flat], (w["name"], e["i"], e["j"])
+    assert "saxpy" in want[2]["burble"] and "dot3" in want[3]["burble"]
+
+
 def _rand_sparse(n, m, density, seed, ints=True):
     rng = np.random.default_rng(seed)
     S = sp.random(n, m, density=density, random_state=rng, format="csr")
