@@ -118,6 +118,16 @@ def bfs(args):
     n, nnz = A.nrows, A.nvals
     dA = A.to_device()
     src = int(np.argmax(np.diff(A.p)))
+    if not getattr(args, "_warm", False):                   # the first traversal loads kernels and fills the memory pool
+        args._warm = True
+        saved = sys.stdout
+        sys.stdout = open(os.devnull, "w")
+        try:
+            dA.free()
+            bfs(args)
+        finally:
+            sys.stdout = saved
+        dA = A.to_device()
     pi_b = np.zeros(n, np.int8); pi_x = np.zeros(n, np.int64)
     pi_b[src] = 1; pi_x[src] = src
     q = Matrix.sparse_vector(n, [src], np.array([src], np.int64))

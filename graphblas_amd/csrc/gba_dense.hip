@@ -906,6 +906,74 @@ static gba_info saxpy4_binned(S sr, const gba_matrix *A, const DenseView &Bv, in
     return GBA_SUCCESS;
 }
 
+// ---- saxpy4 / saxbit over tiles of entries -------------------------------------------------------
+// The kernel above gives every vector of A to a small group of lanes, so one hub vector (10^5 entries in an
+// RMAT graph) keeps its group busy long after the rest of the grid has drained: the BFS step with a bitmap
+// frontier spent 11 ms that way.  Here every workgroup takes DOT_TILE consecutive ENTRIES of A, first notes
+// for each entry which vector owns it (a thread per vector, whole waves for long segments; -1 where B(k,j)
+// is absent), then handles the entries one per lane.  Used with every semiring, positional ones included.
+template <class S, int MODE>
+__global__ void __launch_bounds__(DOT_TILE_THREADS)
+saxpy_tile_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                  const void *__restrict__ Ax_, bool A_iso, DenseView B, MaskViewD M,
+                  typename S::acc_t *__restrict__ Cx, int8_t *__restrict__ Cb, int64_t cvlen,
+                  const int64_t *__restrict__ tile_row) {
+    using X = typename S::x_t; using Z = typename S::z_t;
+    constexpr int NLONG = DOT_TILE / DOT_SEG_SERIAL + 2;
+    __shared__ int owner[DOT_TILE];
+    __shared__ int longlo[NLONG], longhi[NLONG], longv[NLONG];
+    __shared__ int nlongq;
+    const X *Ax = reinterpret_cast<const X *>(Ax_);
+    const X *Bx = reinterpret_cast<const X *>(B.x);
+    const int tid = threadIdx.x;
+    const int64_t j = blockIdx.y;
+    const int64_t pN = Ap[nvecA];
+    const int64_t start = Ap[0] + (int64_t)blockIdx.x * DOT_TILE;
+    if (start >= pN) return;                                  // uniform
+    const int64_t end = (start + DOT_TILE < pN) ? start + DOT_TILE : pN;
+    const int64_t r0 = tile_row[blockIdx.x];
+    const int64_t boff = j * B.vlen, coff = j * cvlen;
+    if (tid == 0) nlongq = 0;
+    __syncthreads();
+    for (int64_t r = r0 + tid; r < nvecA; r += DOT_TILE_THREADS) {
+        const int64_t a0 = Ap[r], a1 = Ap[r + 1];
+        if (a0 >= end) break;
+        const int lo = (int)((a0 > start ? a0 : start) - start), hi = (int)((a1 < end ? a1 : end) - start);
+        if (hi <= lo) continue;
+        const int v = (B.b && !B.b[boff + r]) ? -1 : (int)(r - r0);
+        if (hi - lo > DOT_SEG_SERIAL) {
+            const int q = atomicAdd(&nlongq, 1);
+            longlo[q] = lo; longhi[q] = hi; longv[q] = v;
+            continue;
+        }
+        for (int idx = lo; idx < hi; idx++) owner[idx] = v;
+    }
+    __syncthreads();
+    {
+        const int nq = nlongq, lane = tid & 63;
+        for (int q = tid >> 6; q < nq; q += DOT_TILE_THREADS / 64) {
+            const int hi = longhi[q], v = longv[q];
+            for (int idx = longlo[q] + lane; idx < hi; idx += 64) owner[idx] = v;
+        }
+    }
+    __syncthreads();
+    const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
+#pragma unroll
+    for (int it = 0; it < DOT_TILE_ITEMS; it++) {
+        const int idx = it * DOT_TILE_THREADS + tid;
+        const int64_t p = start + idx;
+        if (p >= end) continue;
+        const int v = owner[idx];
+        if (v < 0) continue;
+        const int64_t k = r0 + v, i = Ai[p];
+        if (MODE == 1 && !maskd_allows(M, i, j)) continue;
+        if (MODE == 1 && sr.add_is_any() && Cb[coff + i]) continue;       // ANY keeps what an earlier product left
+        const Z t = sr.mult(load_x<X>(Ax, p, A_iso, apat), load_x<X>(Bx, boff + k, B.iso, bpat), i, k, j);
+        sr.atomic(&Cx[coff + i], t);
+        if (MODE == 1) Cb[coff + i] = 1;
+    }
+}
+
 // widen / narrow between the stored type and the accumulator type (8/16-bit and bool)
 template <class Z, class ACC>
 __global__ void widen_kernel(const Z *__restrict__ in, ACC *__restrict__ out, int64_t n) {
@@ -972,9 +1040,23 @@ static gba_info saxpy_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask
                 GBA_OK(saxpy4_binned<S>(sr, A, Bv, cvlen, cvdim, cx, st, &done));
                 if (done) return GBA_SUCCESS;
             }
+            DevBuf tile_rows;
+            if (A->nvals >= 4 * DOT_TILE) {                    // entry-balanced tiles; small products keep a group per vector
+                const int64_t ntiles = ceil_div(A->nvals, DOT_TILE);
+                GBA_OK(tile_rows.alloc((size_t)ntiles * 8));
+                int64_t rb = ceil_div(A->nvec, 256); if (rb > 8192) rb = 8192; if (rb < 1) rb = 1;
+                hipLaunchKernelGGL(dot_tile_rows_kernel, dim3((unsigned)rb), dim3(256), 0, st, A->nvec, A->p, (int64_t)DOT_TILE,
+                                   tile_rows.as<int64_t>());
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(saxpy_tile_kernel<S, MODE>), dim3((unsigned)ntiles, (unsigned)cvdim),
+                                   dim3(DOT_TILE_THREADS), 0, st, sr, A->nvec, A->p, A->i, A->x, A->iso, Bv, mv, acc,
+                                   Cb.as<int8_t>(), cvlen, tile_rows.as<int64_t>());
+                GBA_HIP(hipGetLastError());
+                GBA_HIP(hipStreamSynchronize(st));             // tile_rows goes back to the pool on return
+            } else {
             dim3 grid((unsigned)ceil_div(A->nvec * lpr, 256), (unsigned)cvdim);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(saxpy_sd_kernel<S, MODE>), grid, dim3(256), 0, st, sr, A->nvec, A->p, A->i,
                                A->x, A->iso, Bv, mv, lpr, acc, Cb.as<int8_t>(), cvlen);
+            }
             if (WIDEN) {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(narrow_kernel<Z, ACC>), dim3(grid_for(cn)), dim3(256), 0, st, acc, cx, cn);
                 GBA_HIP(hipStreamSynchronize(st));

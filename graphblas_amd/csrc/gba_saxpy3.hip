@@ -254,46 +254,60 @@ bin_fill_kernel(int64_t nvec, const int64_t *__restrict__ work, bool work_is_poi
     for (; idx < nvec; idx += stride) {
         const int64_t w = work_is_pointer_diff ? (work[idx + 1] - work[idx]) : work[idx];
         const int b = bin_of2(w, L, work2, idx, L2);
-        if (b != BIN_EMPTY) {
-            unsigned long long pos = atomicAdd(&cursors[b], 1ull);
-            lists[pos] = idx;
+        // one atomic per wave and bin (atomics on one address are carried out one after the other, about 12 ns
+        // each: a cursor bumped once per vector costs milliseconds at 10^6 vectors)
+        for (int bb = 0; bb < NBINS; bb++) {
+            if (bb == BIN_EMPTY) continue;
+            const unsigned long long mine = __ballot(b == bb);
+            if (!mine) continue;                               // uniform
+            const int lane = threadIdx.x & 63;
+            unsigned long long base = 0;
+            if (lane == __builtin_ctzll(mine)) base = atomicAdd(&cursors[bb], (unsigned long long)__builtin_popcountll(mine));
+            base = __shfl(base, __builtin_ctzll(mine), 64);
+            if (b == bb) lists[base + __builtin_popcountll(mine & ((1ull << lane) - 1))] = idx;
         }
     }
 }
 
 struct Bins {
     DevBuf lists;                 // vector ids grouped by bin
+    DevBuf cnt;                   // per-bin counts, then the fill cursors (device)
     int64_t count[NBINS] = {0, 0, 0, 0, 0};
     int64_t start[NBINS] = {0, 0, 0, 0, 0};
     const int64_t *list(int b) const { return lists.as<int64_t>() + start[b]; }
 };
 
+// cursors[b] = where bin b starts in the grouped list (the empty bin takes no room)
+__global__ void bin_offsets_kernel(const unsigned long long *__restrict__ counts, unsigned long long *__restrict__ cursors) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long off = 0;
+        for (int b = 0; b < NBINS; b++) { cursors[b] = off; if (b != BIN_EMPTY) off += counts[b]; }
+    }
+}
+
 static gba_info build_bins(int64_t nvec, const int64_t *work, bool ptr_diff, BinLimits L, Bins *bins,
                            const int64_t *work2 = nullptr, BinLimits L2 = BinLimits{0, 0, 0}) {
     hipStream_t st = ctx().stream;
-    DevBuf cnt; GBA_OK(cnt.alloc(NBINS * 8));
-    GBA_HIP(hipMemsetAsync(cnt.p, 0, NBINS * 8, st));
+    GBA_OK(bins->cnt.alloc(2 * NBINS * 8));
+    unsigned long long *counts = bins->cnt.as<unsigned long long>(), *cursors = counts + NBINS;
+    GBA_HIP(hipMemsetAsync(counts, 0, NBINS * 8, st));
     GBA_OK(bins->lists.alloc((size_t)(nvec > 0 ? nvec : 1) * 8));
     if (nvec == 0) return GBA_SUCCESS;
     int64_t blocks = ceil_div(nvec, 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, work, ptr_diff, L, work2, L2,
-                       cnt.as<unsigned long long>());
+    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, work, ptr_diff, L, work2, L2, counts);
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(64), 0, st, counts, cursors);
+    hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, work, ptr_diff, L, work2, L2,
+                       cursors, bins->lists.as<int64_t>());
+    GBA_HIP(hipGetLastError());
     unsigned long long h[NBINS];
-    GBA_HIP(hipMemcpyAsync(h, cnt.p, NBINS * 8, hipMemcpyDeviceToHost, st));
-    GBA_HIP(hipStreamSynchronize(st));
-    unsigned long long cur[NBINS];
+    GBA_HIP(hipMemcpyAsync(h, counts, NBINS * 8, hipMemcpyDeviceToHost, st));
+    GBA_HIP(hipStreamSynchronize(st));                     // the one round trip: the host sizes its launches by the counts
     int64_t off = 0;
     for (int b = 0; b < NBINS; b++) {
         bins->count[b] = (int64_t)h[b];
         bins->start[b] = off;
-        cur[b] = (unsigned long long)off;
         if (b != BIN_EMPTY) off += (int64_t)h[b];
     }
-    GBA_HIP(hipMemcpyAsync(cnt.p, cur, NBINS * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, work, ptr_diff, L, work2, L2,
-                       cnt.as<unsigned long long>(), bins->lists.as<int64_t>());
-    GBA_HIP(hipGetLastError());
-    GBA_HIP(hipStreamSynchronize(st));
     return GBA_SUCCESS;
 }
 
@@ -343,28 +357,44 @@ work_scatter_kernel(int64_t n, const int64_t *__restrict__ list, const int64_t *
     for (; idx < n; idx += stride) {
         const int64_t j = list[idx], w = work[j];
         const int b = w > 0 ? 63 - __builtin_clzll((unsigned long long)w) : 0;
-        out[atomicAdd(&cursor[b], 1ull)] = j;
+        // one atomic per wave and class present in it
+        const int lane = threadIdx.x & 63;
+        bool placed = false;
+        while (true) {
+            const unsigned long long todo = __ballot(!placed);
+            if (!todo) break;                                  // uniform
+            const int leader = __builtin_ctzll(todo);
+            const int lb = __shfl(b, leader, 64);
+            const unsigned long long mine = __ballot(!placed && b == lb);
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&cursor[lb], (unsigned long long)__builtin_popcountll(mine));
+            base = __shfl(base, leader, 64);
+            if (!placed && b == lb) { out[base + __builtin_popcountll(mine & ((1ull << lane) - 1))] = j; placed = true; }
+        }
     }
 }
 
+// cursor[b] = number of list entries in heavier classes (classes are filled from 63 down)
+__global__ void work_offsets_kernel(const unsigned long long *__restrict__ hist, unsigned long long *__restrict__ cursor) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long off = 0;
+        for (int b = 63; b >= 0; b--) { cursor[b] = off; off += hist[b]; }
+    }
+}
+
+// out: the ordered list (n ids), followed by the histogram and the cursors; nothing comes back to the host
 static gba_info order_by_work_desc(int64_t n, const int64_t *list, const int64_t *work, DevBuf *out) {
     hipStream_t st = ctx().stream;
-    GBA_OK(out->alloc((size_t)(n > 0 ? n : 1) * 8));
+    const int64_t n1 = n > 0 ? n : 1;
+    GBA_OK(out->alloc((size_t)(n1 + 128) * 8));
     if (n == 0) return GBA_SUCCESS;
-    DevBuf hist; GBA_OK(hist.alloc(64 * 8));
-    GBA_HIP(hipMemsetAsync(hist.p, 0, 64 * 8, st));
+    unsigned long long *hist = out->as<unsigned long long>() + n1, *cursor = hist + 64;
+    GBA_HIP(hipMemsetAsync(hist, 0, 64 * 8, st));
     int64_t blocks = ceil_div(n, 256); if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(work_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, list, work, hist.as<unsigned long long>());
-    unsigned long long h[64], c[64];
-    GBA_HIP(hipMemcpyAsync(h, hist.p, 64 * 8, hipMemcpyDeviceToHost, st));
-    GBA_HIP(hipStreamSynchronize(st));
-    unsigned long long off = 0;
-    for (int b = 63; b >= 0; b--) { c[b] = off; off += h[b]; }
-    GBA_HIP(hipMemcpyAsync(hist.p, c, 64 * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, list, work,
-                       hist.as<unsigned long long>(), out->as<int64_t>());
+    hipLaunchKernelGGL(work_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, list, work, hist);
+    hipLaunchKernelGGL(work_offsets_kernel, dim3(1), dim3(64), 0, st, hist, cursor);
+    hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, list, work, cursor, out->as<int64_t>());
     GBA_HIP(hipGetLastError());
-    GBA_HIP(hipStreamSynchronize(st));              // c[] is read by the copy above
     return GBA_SUCCESS;
 }
 
@@ -761,13 +791,14 @@ __global__ void fill_acc_kernel(ACC *p, int64_t n, ACC v) {
 // share one Hf/Hx workspace through atomics (Source/GB_AxB_saxpy3_slice_balanced.c:560-771,
 // Source/Template/GB_AxB_saxpy3_fineGus_phase2.c).  Here the whole grid is the team: every wavefront takes
 // neighbours k of B(:,j) and scatters A(:,k) into a dense accumulator Hx[cvlen] with the monoid's atomic,
-// marking touched indices in the bitmap Hf; columns longer than TEAM_LONG are shared by the whole grid.
+// marking touched indices in the bitmap Hf; columns longer than TEAM_LONG are shared by groups of workgroups.
 // The products are formed once, during the symbolic phase (the count is the number of marks); the
 // numeric phase only gathers.  Entries come out in no particular order (C is returned jumbled).
 static constexpr int TEAM_MAX_VECTORS = 32;
 static constexpr int64_t TEAM_MIN_FLOPS = 200000;
 static constexpr int TEAM_THREADS = 256;
 static constexpr int64_t TEAM_LONG = 8192;
+static constexpr int TEAM_LONG_WGS = 8;           // workgroups that share one long column (the grid is a multiple of it)
 
 __global__ void __launch_bounds__(256)
 team_select_kernel(int64_t nvec, const int64_t *__restrict__ vflops, int64_t min_flops,
@@ -794,9 +825,11 @@ __device__ inline void team_update(const S &sr, const SpView &A, const SpView &B
                                    typename S::acc_t *__restrict__ Hx, uint64_t *__restrict__ Hf) {
     const int64_t i = A.i[pA];
     if (!mask_allows(M, i, j)) return;
-    sr.atomic(&Hx[i], product(sr, A, B, apat, bpat, i, k, j, pA, pB));
     const uint64_t bit = 1ull << (i & 63);
-    if (!(ld_agent(&Hf[i >> 6]) & bit)) atomicOr(reinterpret_cast<unsigned long long *>(&Hf[i >> 6]), (unsigned long long)bit);
+    const bool seen = (ld_agent(&Hf[i >> 6]) & bit) != 0;
+    if (seen && sr.add_is_any()) return;                      // ANY keeps the value some earlier product left there
+    sr.atomic(&Hx[i], product(sr, A, B, apat, bpat, i, k, j, pA, pB));
+    if (!seen) atomicOr(reinterpret_cast<unsigned long long *>(&Hf[i >> 6]), (unsigned long long)bit);
 }
 
 template <class S>
@@ -822,11 +855,14 @@ template <class S>
 __global__ void __launch_bounds__(TEAM_THREADS)
 team_long_kernel(S sr, int64_t j, SpView A, SpView B, MaskView M, typename S::acc_t *__restrict__ Hx,
                  uint64_t *__restrict__ Hf, const unsigned long long *__restrict__ nlong, const int64_t *__restrict__ longq) {
-    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    // groups of TEAM_LONG_WGS workgroups take the long columns in turn: a frontier of hub vertices queues
+    // thousands of them, and a pass of the whole grid over each costs a grid-wide round trip per column
+    const int64_t grp = blockIdx.x / TEAM_LONG_WGS, ngrp = gridDim.x / TEAM_LONG_WGS;
+    const int64_t gt = (int64_t)(blockIdx.x % TEAM_LONG_WGS) * blockDim.x + threadIdx.x, nt = (int64_t)TEAM_LONG_WGS * blockDim.x;
     const int64_t pB0 = B.p[j];
     const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
-    const unsigned long long n = *nlong;
-    for (unsigned long long q = 0; q < n; q++) {
+    const int64_t n = (int64_t)*nlong;
+    for (int64_t q = grp; q < n; q += ngrp) {
         const int64_t t = longq[q], k = B.i[pB0 + t];
         const int64_t pA1 = A.p[k + 1];
         for (int64_t pA = A.p[k] + gt; pA < pA1; pA += nt) team_update(sr, A, B, M, apat, bpat, j, k, pA, pB0 + t, Hx, Hf);
@@ -835,21 +871,25 @@ team_long_kernel(S sr, int64_t j, SpView A, SpView B, MaskView M, typename S::ac
 
 __global__ void __launch_bounds__(256)
 team_count_kernel(int64_t nf, const uint64_t *__restrict__ Hf, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long part[4];
     int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     unsigned long long c = 0;
     for (; w < nf; w += stride) c += (unsigned long long)__builtin_popcountll(Hf[w]);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { c = part[0] + part[1] + part[2] + part[3]; if (c) atomicAdd(out, c); }
 }
 
 template <class S>
 __global__ void __launch_bounds__(256)
 team_gather_kernel(int64_t nf, const uint64_t *__restrict__ Hf, const typename S::acc_t *__restrict__ Hx,
-                   unsigned long long *__restrict__ cursor, int64_t pC0, int64_t *__restrict__ Ci,
-                   typename S::z_t *__restrict__ Cx) {
+                   unsigned long long *__restrict__ cursor, const int64_t *__restrict__ Cp, int64_t j,
+                   int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx) {
     using Z = typename S::z_t;
+    const int64_t pC0 = Cp[j];
     const int lane = threadIdx.x & 63;
     int64_t w0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1756,7 +1796,7 @@ struct Saxpy3Plan {
     int64_t *Cp, *Ci; void *Cx;
     PhaseClock *clock = nullptr;
     int ev_num[5] = {-1, -1, -1, -1, -1};   // before wave, blk1, blk2, global, after global
-    bool A_sorted = false;                  // vectors of A in index order: panel kernels usable
+    bool use_panels = false;                // A sorted and the product large enough: panel kernels for the heavy vectors
     int64_t maxdeg = 0;                     // longest vector of B
     const int64_t *vflops = nullptr;        // per-vector flop count (device)
     // team vectors: ids (host), their workspaces one after the other (device)
@@ -1783,7 +1823,7 @@ static gba_info run_team_products(const S &sr, Saxpy3Plan &P, int64_t *cnt) {
     GBA_OK(longq.alloc((size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
     GBA_HIP(hipMemsetAsync(nlong.p, 0, (size_t)nteam * 8, st));
     const unsigned grid = (unsigned)(ctx().num_cu * 8);
-    int64_t cb = ceil_div(nf, 256); if (cb > 4096) cb = 4096;
+    int64_t cb = ceil_div(nf, 256 * 8); if (cb > 512) cb = 512; if (cb < 1) cb = 1;
     for (int64_t q = 0; q < nteam; q++) {
         const int64_t j = P.team[(size_t)q];
         ACC *hx = Hx + q * P.cvlen; uint64_t *hf = P.team_Hf + q * nf;
@@ -1812,11 +1852,9 @@ static gba_info run_team_gather(const S &sr, Saxpy3Plan &P) {
     int64_t gb = ceil_div(nf, 256); if (gb > 4096) gb = 4096;
     for (int64_t q = 0; q < nteam; q++) {
         const int64_t j = P.team[(size_t)q];
-        int64_t pC0 = 0;
-        GBA_OK(dev_read_i64(P.Cp + j, &pC0));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(team_gather_kernel<S>), dim3((unsigned)gb), dim3(256), 0, st, nf,
                            P.team_Hf + q * nf, reinterpret_cast<const ACC *>(P.team_Hx) + q * P.cvlen,
-                           cursor.as<unsigned long long>() + q, pC0, P.Ci, reinterpret_cast<Z *>(P.Cx));
+                           cursor.as<unsigned long long>() + q, P.Cp, j, P.Ci, reinterpret_cast<Z *>(P.Cx));
     }
     GBA_HIP(hipGetLastError());
     GBA_HIP(hipStreamSynchronize(st));
@@ -1853,7 +1891,7 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
     }
     GBA_HIP(hipGetLastError());
     mark(3);
-    if (nb.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) {
+    if (nb.count[BIN_GLOBAL] > 0 && P.use_panels && P.maxdeg < PANEL_MAX_DEG) {
         int64_t nblocks = (int64_t)ctx().num_cu;
         if (nblocks > nb.count[BIN_GLOBAL]) nblocks = nb.count[BIN_GLOBAL];
         // tasks: heaviest first, hub vectors cut at recorded boundaries
@@ -1949,7 +1987,7 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
                            sb.count[BIN_BLK2], sb.list(BIN_BLK2), P.A, P.B, P.M, P.lpa, cnt);
     }
     GBA_HIP(hipGetLastError());
-    if (sb.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) {
+    if (sb.count[BIN_GLOBAL] > 0 && P.use_panels && P.maxdeg < PANEL_MAX_DEG) {
         int64_t nblocks = (int64_t)ctx().num_cu;
         if (nblocks > sb.count[BIN_GLOBAL]) nblocks = sb.count[BIN_GLOBAL];
         DevBuf scratch, next;
@@ -2024,16 +2062,21 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         GBA_OK(team_list.alloc(TEAM_MAX_VECTORS * 8));
         if (nvec > 0) {
             int64_t blocks = ceil_div(nvec, 256); if (blocks > 2048) blocks = 2048;
+            // With only a few vectors in all (a frontier step has one) nothing else can fill the chip: every vector
+            // too heavy for a workgroup's LDS table is then worked on by the whole grid.
+            const int64_t min_flops = (nvec <= TEAM_MAX_VECTORS) ? (int64_t)SYM_BLK1_MAX : TEAM_MIN_FLOPS;
             hipLaunchKernelGGL(team_select_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, vflops.as<int64_t>(),
-                               TEAM_MIN_FLOPS, tc.as<unsigned long long>(), team_list.as<int64_t>(), TEAM_MAX_VECTORS);
+                               min_flops, tc.as<unsigned long long>(), team_list.as<int64_t>(), TEAM_MAX_VECTORS);
         }
         int64_t nteam = 0;
         GBA_OK(dev_read_i64(tc.as<int64_t>(), &nteam));
         const size_t acc_size = type_size(c.ztype) < 4 ? 4 : type_size(c.ztype);
         const int64_t nf = (P.cvlen + 63) >> 6;
         size_t free_b = 0, total_b = 0, idle_b = 0;
-        GBA_HIP(hipMemGetInfo(&free_b, &total_b));
-        gba_pool_stats(&idle_b, nullptr);
+        if (nteam > 0) {                                     // (a driver query: not on the path of calls without a team)
+            GBA_HIP(hipMemGetInfo(&free_b, &total_b));
+            gba_pool_stats(&idle_b, nullptr);
+        }
         const size_t need = (size_t)nteam * ((size_t)P.cvlen * acc_size + (size_t)nf * 8);
         int64_t team_max = TEAM_MAX_VECTORS;                 // GBA_TEAM_MAX_VECTORS=0 turns the team path off (tests)
         if (const char *e = getenv("GBA_TEAM_MAX_VECTORS")) { team_max = atoll(e); if (team_max > TEAM_MAX_VECTORS) team_max = TEAM_MAX_VECTORS; }
@@ -2054,9 +2097,12 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     }
     // With sorted A the bitmap panel kernel also takes the vectors of the second block bin: it has no table to
     // clear per vector and records the numeric panel boundaries.
-    const int64_t sym_blk2_max = A->jumbled ? SYM_BLK2_MAX : SYM_BLK1_MAX;
+    // The panel kernels need sorted A and read its indices from a 32-bit copy made per call: a pass over all of
+    // A, which a product with a small B (a frontier against a large graph) must not pay for.  Such products
+    // keep the memory-side accumulator kernels.
+    P.use_panels = !A->jumbled && B->nvals >= A->nvals / 32;
+    const int64_t sym_blk2_max = P.use_panels ? SYM_BLK1_MAX : SYM_BLK2_MAX;
     GBA_OK(build_bins(nvec, symflops, false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, sym_blk2_max}, &P.sym));
-    P.A_sorted = !A->jumbled;
     P.vflops = vflops.as<int64_t>();
     if (P.sym.count[BIN_GLOBAL] > 0 || !P.team.empty()) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
     // the panel kernels read the indices of A from a 32-bit copy (vlen < 2^31 was checked above)
@@ -2075,7 +2121,7 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         return GBA_SUCCESS;
     };
     DevBuf bstart, bounds;
-    if (P.sym.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) {
+    if (P.sym.count[BIN_GLOBAL] > 0 && P.use_panels && P.maxdeg < PANEL_MAX_DEG) {
         GBA_OK(narrow_A());
         GBA_OK(bstart.alloc((size_t)(nvec + 1) * 8));
         int64_t blocks = ceil_div(nvec + 1, 256); if (blocks > 4096) blocks = 4096;
@@ -2114,7 +2160,7 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
                           vflops.as<int64_t>(), BinLimits{2048, 16384, 65536}));
     }
     if (P.num.count[BIN_GLOBAL] > 0 && P.maxdeg == 0) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
-    if (P.num.count[BIN_GLOBAL] > 0 && P.A_sorted && P.maxdeg < PANEL_MAX_DEG) GBA_OK(narrow_A());
+    if (P.num.count[BIN_GLOBAL] > 0 && P.use_panels && P.maxdeg < PANEL_MAX_DEG) GBA_OK(narrow_A());
 
     // phases 3/4: Cp = cumsum (cnt)
     GBA_OK(dev_cumsum_i64(Cp.as<int64_t>(), nvec, st));

@@ -5,7 +5,7 @@ import scipy.sparse as sp
 
 from graphblas_amd import Matrix, Type, Sparsity, gen
 from oracle import oracle
-from util import assert_same
+from util import assert_same, assert_sums_within_bound
 
 pytestmark = pytest.mark.gpu
 
@@ -104,9 +104,11 @@ def test_dot2_uniform_fp32_within_tolerance(gba):
     B = Matrix.full_vector(x)
     dA, dB = A.to_device(), B.to_device()
     out, _ = gba.AxB_dot2(None, False, False, dA, dB, "PLUS_TIMES_FP32")
-    # tree reduction over the lanes of a group vs the CPU's left-to-right sum: the reference's
-    # 64*eps bound per entry, scaled by log2 of the longest vector (~2^11 entries)
-    assert_same(out.to_host(), oracle.dot2(None, False, False, A, B, "PLUS_TIMES_FP32"), exact=False, rtol_scale=16)
+    # LDS tiles and wave reductions against the CPU's left-to-right sum: positive values, so both are held to the
+    # a-priori bound with the length of A(:,i) as the number of products behind y(i)
+    got, want = out.to_host(), oracle.dot2(None, False, False, A, B, "PLUS_TIMES_FP32")
+    rows = got.coo()[0]
+    assert_sums_within_bound(got, want, np.diff(A.p)[rows], what="dot2 fp32")
     _free(dA, dB, out)
 
 
@@ -237,6 +239,69 @@ def test_saxbit(gba, sr, t, mask):
     dM = M.to_device() if M is not None else None
     out, _ = gba.AxB_saxbit(dM, comp, True, dA, dB, sr)
     assert_same(out.to_host(), oracle.saxbit(M, comp, True, A, B, sr), exact=True, what=sr)
+    _free(dA, dB, dM, out)
+
+
+def _hub_matrix(n, inner, t, seed):
+    """A sparse by column with more than four tiles of entries: one vector longer than a tile, a run of empty
+    vectors, a destination hit from thousands of vectors; small integer values."""
+    rng = np.random.default_rng(seed)
+    dest = np.concatenate([rng.integers(0, n, 40_000), np.full(3_000, 7), rng.choice(n, 9_000, replace=False)])
+    k = np.concatenate([rng.integers(0, inner // 2, 40_000), rng.choice(inner // 2, 3_000, replace=False), np.full(9_000, 5)])
+    S = sp.coo_matrix((rng.integers(1, 3, len(k)).astype(np.float64), (dest, k)), shape=(n, inner)).tocsc()
+    S.sum_duplicates(); S.data = np.minimum(S.data, 3)
+    assert S.nnz > 4 * 2048
+    return Matrix.from_scipy(S, type=t, by_row=False)
+
+
+@pytest.mark.parametrize("sr,t", [("PLUS_TIMES_FP64", Type.FP64), ("MIN_SECONDJ_INT64", Type.INT64), ("MAX_TIMES_INT8", Type.INT8),
+                                  ("LOR_LAND_BOOL", Type.BOOL), ("PLUS_FIRSTI_INT32", Type.INT32)])
+@pytest.mark.parametrize("bkind", ["full", "bitmap"])
+def test_saxpy4_over_entry_tiles(gba, sr, t, bkind):
+    """Enough entries for the entry-balanced kernel (but too few, or a semiring or a bitmap B unfit, for the
+    destination bins): hub vector, empty vectors, positional multipliers, narrow types widened and narrowed."""
+    from graphblas_amd.binding import NP_TYPES
+    rng = np.random.default_rng(23)
+    n, inner = 15_000, 12_000
+    A = _hub_matrix(n, inner, t, 24)
+    B = Matrix.dense(rng.integers(0, 3, (inner, 2)).astype(NP_TYPES[t]),
+                     present=(rng.random((inner, 2)) < 0.6) if bkind == "bitmap" else None, by_row=False)
+    C0 = Matrix.dense(rng.integers(0, 3, (n, 2)).astype(NP_TYPES[t]), by_row=False)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    assert gba.AxB_saxpy4(dC, dA, dB, sr) is not None
+    assert_same(dC.to_host(), oracle.saxpy4(C0, A, B, sr), exact=True, what=sr)
+    _free(dA, dB, dC)
+
+
+@pytest.mark.parametrize("sr,t", [("ANY_SECONDI_INT64", Type.INT64), ("PLUS_TIMES_INT32", Type.INT32), ("MIN_PLUS_FP64", Type.FP64)])
+@pytest.mark.parametrize("mask", [None, ("bitmap", True), ("sparse", False)])
+def test_saxbit_over_entry_tiles(gba, sr, t, mask):
+    """The BFS step with a bitmap frontier at a size that takes the entry-balanced kernel.  ANY may keep any
+    contributing product: for it only the pattern is compared, and that every value is one of the candidates."""
+    from graphblas_amd.binding import NP_TYPES
+    rng = np.random.default_rng(25)
+    n, inner = 15_000, 12_000
+    A = _hub_matrix(n, inner, t, 26)
+    B = Matrix.dense(rng.integers(1, 4, (inner, 1)).astype(NP_TYPES[t]), present=rng.random((inner, 1)) < 0.4, by_row=False)
+    M, comp = None, False
+    if mask is not None:
+        kind, comp = mask
+        if kind == "bitmap":
+            M = Matrix.dense(np.ones((n, 1), np.int8), present=rng.random((n, 1)) < 0.5, by_row=False)
+        else:
+            M = Matrix.from_scipy(sp.random(n, 1, density=0.4, random_state=rng, format="csc"), type=Type.FP64, by_row=False)
+    dA, dB = A.to_device(), B.to_device()
+    dM = M.to_device() if M is not None else None
+    out, _ = gba.AxB_saxbit(dM, comp, True, dA, dB, sr)
+    got, want = out.to_host(), oracle.saxbit(M, comp, True, A, B, sr)
+    if sr.startswith("ANY"):
+        assert_same(got, want, check_values=False, what=sr)
+        r, c, v = got.coo()
+        S, present = A.to_scipy().tocsr(), np.asarray(B.b).ravel() != 0
+        for i, k in list(zip(r, v))[::37]:                      # SECONDI: the value is the index k of a contributing B(k)
+            assert present[k] and S[i, k] != 0, (i, k)
+    else:
+        assert_same(got, want, exact=True, what=sr)
     _free(dA, dB, dM, out)
 
 

@@ -5,7 +5,7 @@ import scipy.sparse as sp
 
 from graphblas_amd import Matrix, Type, Sparsity, gen
 from oracle import oracle
-from util import assert_same
+from util import assert_same, assert_sums_within_bound
 
 pytestmark = pytest.mark.gpu
 
@@ -45,9 +45,11 @@ def test_rmat_plus_times_fp64(gba, scale, ef):
     A = gen.rmat(scale, ef, seed=42, by_row=False)
     got, rep, _ = _run(gba, A, A, "PLUS_TIMES_FP64")
     want = oracle.saxpy3(None, False, False, A, A, "PLUS_TIMES_FP64")
-    # summation order differs (atomics): the reference's own 64*eps rule, scaled by the
-    # longest sum (number of terms per entry is bounded by the row length)
-    assert_same(got, want, exact=False, rtol_scale=8)
+    # the summation order differs (LDS and memory atomics against the CPU's left-to-right sum); the values are
+    # positive, so both sides are held to the a-priori bound with the number of products behind every C(i,j)
+    P = A.to_scipy().copy(); P.data[:] = 1
+    counts = (P @ P).tocsr(); counts.sort_indices()
+    assert_sums_within_bound(got, want, counts.tocoo().data, what=f"RMAT-{scale}")
 
 
 def test_rmat_integer_valued_is_bit_exact(gba):

@@ -8,7 +8,7 @@ from graphblas_amd.binding import Type, NP_TYPES
 FP_RTOL = {Type.FP32: 64 * np.finfo(np.float32).eps, Type.FP64: 64 * np.finfo(np.float64).eps}
 
 
-def assert_same(got, want, exact=None, check_values=True, rtol_scale=1.0, what=""):
+def assert_same(got, want, exact=None, check_values=True, what=""):
     """Compare two host Matrix objects as sets of (row, col, value)."""
     assert got.type == want.type, f"{what}: type {got.type} != {want.type}"
     assert (got.nrows, got.ncols) == (want.nrows, want.ncols), f"{what}: shape"
@@ -28,8 +28,29 @@ def assert_same(got, want, exact=None, check_values=True, rtol_scale=1.0, what="
         bad = np.nonzero(~same)[0]
         assert len(bad) == 0, f"{what}: {len(bad)} values differ, first at ({gr[bad[0]]},{gc[bad[0]]}): {gv[bad[0]]} vs {wv[bad[0]]}"
     else:
-        rtol = FP_RTOL[got.type] * rtol_scale
+        rtol = FP_RTOL[got.type]
         np.testing.assert_allclose(gv.astype(np.float64), wv.astype(np.float64), rtol=rtol, atol=0, err_msg=what)
+
+
+def assert_sums_within_bound(got, want, terms, what=""):
+    """Two floating-point evaluations, in different orders, of sums of POSITIVE products: same pattern, and
+    every value pair within the a-priori bound.  A sum of m products evaluated in any order is within
+    (m + 1) * u * exact of the exact sum (u the unit roundoff: one rounding per product, at most m - 1 roundings
+    on the path of any term through the additions, first-order), so two such evaluations differ by at most
+    2 * (m + 1) * u * exact; `terms` gives m per entry in the (row, col) order of Matrix.coo()."""
+    assert got.type == want.type and got.type in FP_RTOL, what
+    gr, gc, gv = got.coo()
+    wr, wc, wv = want.coo()
+    assert np.array_equal(gr, wr) and np.array_equal(gc, wc), f"{what}: pattern differs"
+    terms = np.asarray(terms, np.float64)
+    assert len(terms) == len(gv), f"{what}: {len(terms)} term counts for {len(gv)} entries"
+    u = np.finfo(NP_TYPES[got.type]).eps / 2
+    a, b = gv.astype(np.float64), wv.astype(np.float64)
+    assert np.all(b > 0), f"{what}: the bound is stated for positive sums"
+    ratio = np.abs(a - b) / (2 * (terms + 1) * u * b)
+    worst = int(np.argmax(ratio)) if len(ratio) else 0
+    assert len(ratio) == 0 or ratio[worst] <= 1.0, \
+        f"{what}: ({gr[worst]},{gc[worst]}) {a[worst]!r} vs {b[worst]!r}: {ratio[worst]:.2f} x the bound for {int(terms[worst])} terms"
 
 
 def dense_of(M):
@@ -42,7 +63,7 @@ def dense_of(M):
     return present, value
 
 
-def assert_dense_same(got, present, value, exact=None, rtol_scale=1.0, what=""):
+def assert_dense_same(got, present, value, exact=None, what=""):
     gp, gv = dense_of(got)
     assert np.array_equal(gp, present), f"{what}: pattern differs ({gp.sum()} vs {present.sum()} entries)"
     if exact is None:
@@ -51,4 +72,4 @@ def assert_dense_same(got, present, value, exact=None, rtol_scale=1.0, what=""):
     if exact:
         assert np.array_equal(a, b), f"{what}: values differ"
     else:
-        np.testing.assert_allclose(a.astype(np.float64), b.astype(np.float64), rtol=FP_RTOL[got.type] * rtol_scale, atol=0, err_msg=what)
+        np.testing.assert_allclose(a.astype(np.float64), b.astype(np.float64), rtol=FP_RTOL[got.type], atol=0, err_msg=what)
