@@ -216,7 +216,9 @@ def main():
             "numeric_bin_vectors_rank0": [int(x) // max(args.steps, 1) for x in stats["bins"]],
             "roofline": {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(f"RMAT-{args.scale} ef={args.edge_factor}", names[k]),
+                         **measured_counters(f"RMAT-{args.scale} ef={args.edge_factor}", names[k]),
+                         # what holds the kernel below the HBM line (see the per-phase stopwatch in DESIGN.md)
+                         "limiter": "latency: dependent memory/LDS round trips per panel, too few bytes in flight per CU",
                          "avg_launch_ms": round(float(k_ms), 3), "algorithmic_bytes_per_launch": int(k_bytes),
                          "streaming_model_GBps": round(streamed, 2),
                          "kernel_multiply_adds_per_launch": int(stats["bin_madds"][k] // launches)},
@@ -268,18 +270,36 @@ def spmv_leg(g, torch, A, Bp, Bi, Bx, dev, args, iters=20):
            "algorithmic_bytes": int(alg), "unit": "GB/s", "peak": HBM_PEAK_GBS, "bound": "hbm"}
     out.update(mxv)
     out["vxm"] = vxm                                        # y' += x'*A on the same matrix (scatter form)
+    try:                                                     # HBM bytes per launch of the gather kernel, from the committed PMC passes
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            rec = json.load(f).get(f"RMAT-{args.scale} ef={args.edge_factor} spmv")
+        for name, k in (rec or {}).get("kernels", {}).items():
+            if name.startswith("dot_tile_kernel") and name.rstrip().endswith(", 0>"):
+                out["traffic"] = k.get("traffic")
+                out["lds_bank_conflict_frac"] = k.get("lds_bank_conflict_frac")
+                out["counters_from"] = "profiles/ " + str(rec.get("round", ""))
+    except (OSError, ValueError, KeyError):
+        pass
     return out
 
 
-def measured_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/hbm_traffic.json); None when this workload has not been profiled."""
+def measured_counters(workload, kernel):
+    """Per launch of `kernel`, from the committed rocprofv3 PMC passes of this same command (profiles/hbm_traffic.json,
+    written by profiles/summarize_round.py): HBM bytes (`traffic`), the share of LDS cycles lost to bank conflicts and
+    the waves resident per busy CU.  `traffic` is None when this workload has not been profiled."""
+    out = {"traffic": None}
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             rec = json.load(f).get(workload)
-        return int(rec["traffic"]) if rec and rec["kernel"] == kernel else None
+        if rec and rec["kernel"].split("<")[0] == kernel.split("<")[0]:
+            out["traffic"] = int(rec["traffic"])
+            for key in ("lds_bank_conflict_frac", "waves_per_busy_cu"):
+                if key in rec:
+                    out[key] = rec[key]
+            out["counters_from"] = "profiles/ " + str(rec.get("round", ""))
     except (OSError, ValueError, KeyError):
-        return None
+        pass
+    return out
 
 
 def cpu_baseline(A, rf, target_madds):
@@ -300,6 +320,9 @@ def cpu_baseline(A, rf, target_madds):
     C = oracle.saxpy3(None, False, False, A, As, "PLUS_TIMES_FP64")      # internal operands: (A_I, B_I) = (A, sample rows)
     dt = time.perf_counter() - t
     return {"value": round(2.0 * madds / dt / 1e9, 4), "unit": "GFLOP/s", "cores": oracle.num_threads(), "kind": "port",
+            # what pins the port: the reference's printed results for its two user-type demos, replayed by the oracle
+            "validated_by": "oracle vs Demo/Output/gauss_demo.out and wildtype_demo.out (tests/test_oracle.py); "
+                            "the reference library itself does not build here",
             "sample": f"rows 0,{stride},{2 * stride},... of A ({len(rows)} rows, {madds} multiply-adds, "
                       f"{100.0 * madds / total:.2f}% of the job, nnz(C sample)={C.nvals}) times the whole A; {dt:.1f} s",
             "seconds": round(dt, 2)}

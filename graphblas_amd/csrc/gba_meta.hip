@@ -729,6 +729,22 @@ static gba_info run_saxpy(gba_matrix *T, const Call &k, const gba_matrix *C_in, 
 }
 
 // GB_mxm + GB_AxB_meta
+// keep one value of a result whose entries are all equal by the rule of axb_iso: the value is read from the
+// computed result (sparse or full T; a bitmap T stays as it is)
+static gba_info shrink_to_iso(gba_matrix *T) {
+    if (T->iso || T->nvals <= 0 || is_bitmap(T) || T->nzombies) return GBA_SUCCESS;
+    const size_t zs = type_size(T->type);
+    int64_t first = 0;
+    if (is_sparse(T) || is_hyper(T)) GBA_OK(dev_read_i64(T->p, &first));      // views may start at p[0] != 0
+    void *one = gba_malloc(zs);
+    if (!one) GBA_FAIL(GBA_OUT_OF_MEMORY, "iso value");
+    GBA_HIP(hipMemcpyAsync(one, static_cast<const char *>(T->x) + (size_t)first * zs, zs, hipMemcpyDeviceToDevice, ctx().stream));
+    GBA_HIP(hipStreamSynchronize(ctx().stream));
+    gba_free(T->x);
+    T->x = one; T->iso = true;
+    return GBA_SUCCESS;
+}
+
 static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
     GBA_OK(require_init());
     Exec ex;
@@ -1000,7 +1016,11 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
     }
     const bool c_empty = (nnz_held(C) == 0) && !is_full(C);
     if (!k.has_accum && (!M || ex.mask_applied) && (k.C_replace || c_empty)) {
-        // transplant (Source/GB_mxm.c:168-199)
+        // transplant (Source/GB_mxm.c:168-199); an iso-valued product is handed over as iso (Source/GB_AxB_iso.c)
+        if (!cast_T && axb_iso(k.A_in, k.B_in, k.semiring, k.flipxy)) {
+            info = shrink_to_iso(&T);
+            if (info != GBA_SUCCESS) { gba_matrix_free_content(&T); return info; }
+        }
         free_unaliased(C, k);
         const bool csc = C->is_csc;
         *C = T;

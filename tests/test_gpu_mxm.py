@@ -370,3 +370,27 @@ def test_jumbled_results_feed_the_next_call(gba):
     p, v = oracle.mxm_spec(C0, M, None, "PLUS_TIMES_FP64", B, C1, "ST1")
     assert_dense_same(d3.to_host(), p, v, exact=True, what="jumbled dot operand")
     assert d1.to_host().jumbled                              # the caller's matrix is untouched
+
+
+@pytest.mark.parametrize("sr,t,b_iso,want_iso", [("ANY_PAIR_BOOL", Type.BOOL, False, True), ("MIN_SECOND_FP64", Type.FP64, True, True),
+                                                 ("MIN_SECOND_FP64", Type.FP64, False, False), ("PLUS_PAIR_INT64", Type.INT64, False, False),
+                                                 ("LOR_LAND_BOOL", Type.BOOL, True, False)])
+def test_iso_valued_products_come_back_iso(gba, sr, t, b_iso, want_iso):
+    """C = A*B replaces an empty C: when the semiring and the operands make every entry equal
+    (Source/GB_AxB_iso.c:117-330: PAIR under a monoid that keeps 1, SECOND/FIRST of an iso operand under
+    ANY/MIN/MAX/LOR/LAND/BOR/BAND, two iso operands) C is handed over iso with one stored value."""
+    n = 70
+    A, B = _rand(n, n, 0.1, 31, t=t, lo=1, hi=2), _rand(n, n, 0.1, 32, t=t, lo=1, hi=4)
+    if b_iso:
+        B = Matrix(B.vlen, B.vdim, t, Sparsity.SPARSE, B.is_csc, p=B.p, i=B.i, x=np.array([3], NP_TYPES[t]), iso=True, nvals=B.nvals)
+    C0 = Matrix.sparse_empty(n, n, t)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    gba.mxm(dC, None, None, sr, dA, dB, "")
+    got = dC.to_host()
+    assert got.iso == want_iso
+    if want_iso:
+        assert len(got.x) == 1
+    p, v = oracle.mxm_spec(C0, None, None, sr, A, B, "")
+    assert_dense_same(got, p, v, exact=True, what=sr)
+    for d in (dA, dB, dC):
+        d.free()
