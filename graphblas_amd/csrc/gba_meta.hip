@@ -745,7 +745,7 @@ static gba_info shrink_to_iso(gba_matrix *T) {
     return GBA_SUCCESS;
 }
 
-static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
+static gba_info mxm_driver_sparse_C(Call k, gba_report *report, bool select_only) {
     GBA_OK(require_init());
     Exec ex;
     ex.rep.flops = -1;
@@ -761,7 +761,7 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
     (void)M_user;
     const gba_matrix *A_in = k.A_in, *B_in = k.B_in;
     // hypersparse operands are given to the kernels in sparse form (a pointer array over every vector);
-    // the result is sparse, never hypersparse
+    // a hypersparse C is made hypersparse again at the end (mxm_driver)
     gba_matrix Msp, Asp, Bsp;
     if (k.M && is_hyper(k.M)) { GBA_OK(hyper_to_sparse(k.M, &Msp, ex.owned)); k.M = &Msp; }
     if (is_hyper(A_in)) { GBA_OK(hyper_to_sparse(A_in, &Asp, ex.owned)); k.A_in = A_in = &Asp; }
@@ -1057,6 +1057,15 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
     }
     gba_matrix_free_content(&T);
     GBA_FAIL(GBA_NOT_IMPLEMENTED, "C<M> = accum (C,T) with C of sparsity %d and T of sparsity %d", C->sparsity, T.sparsity);
+}
+
+// A C that comes in hypersparse goes back hypersparse: the kernels work on its sparse form (a pointer per vector),
+// and the list of non-empty vectors is rebuilt from the result.
+static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
+    const bool C_was_hyper = k.C && is_hyper(k.C);
+    const gba_info info = mxm_driver_sparse_C(k, report, select_only);
+    if (info != GBA_SUCCESS || !C_was_hyper || select_only || !is_sparse(k.C) || k.C->mem != GBA_MEM_DEVICE) return info;
+    return sparse_to_hyper(k.C);
 }
 
 }  // namespace gba

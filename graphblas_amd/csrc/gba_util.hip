@@ -465,6 +465,53 @@ gba_info hyper_to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *>
     return GBA_SUCCESS;
 }
 
+// ------------------------------------------------------ sparse -> hypersparse --
+// The way back (Source/GB_convert_sparse_to_hyper.c): h lists the non-empty vectors, p keeps one pointer per
+// listed vector; i and x stay.  C must own its arrays (its p is replaced).
+__global__ void __launch_bounds__(256)
+hyper_flag_kernel(int64_t nvec, const int64_t *__restrict__ p, int64_t *__restrict__ flag) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; j < nvec; j += stride) flag[j] = (p[j + 1] > p[j]) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+hyper_gather_kernel(int64_t nvec, const int64_t *__restrict__ p, const int64_t *__restrict__ pos,
+                    int64_t *__restrict__ h, int64_t *__restrict__ hp) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (j == 0) hp[pos[nvec]] = p[nvec];
+    for (; j < nvec; j += stride)
+        if (p[j + 1] > p[j]) { h[pos[j]] = j; hp[pos[j]] = p[j]; }
+}
+
+gba_info sparse_to_hyper(gba_matrix *C) {
+    GBA_OK(require_init());
+    if (!is_sparse(C) || C->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_INVALID_VALUE, "sparse_to_hyper: sparsity %d", C->sparsity);
+    hipStream_t st = ctx().stream;
+    const int64_t nvec = C->nvec;
+    DevBuf pos;
+    GBA_OK(pos.alloc((size_t)(nvec + 1) * 8));
+    int64_t blocks = ceil_div(nvec, 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(hyper_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, C->p, pos.as<int64_t>());
+    GBA_OK(dev_cumsum_i64(pos.as<int64_t>(), nvec, st));
+    int64_t nonempty = 0;
+    GBA_OK(dev_read_i64(pos.as<int64_t>() + nvec, &nonempty));
+    DevBuf h, hp;
+    GBA_OK(h.alloc((size_t)(nonempty > 0 ? nonempty : 1) * 8));
+    GBA_OK(hp.alloc((size_t)(nonempty + 1) * 8));
+    hipLaunchKernelGGL(hyper_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, C->p, pos.as<int64_t>(),
+                       h.as<int64_t>(), hp.as<int64_t>());
+    GBA_HIP(hipGetLastError());
+    GBA_HIP(hipStreamSynchronize(st));
+    gba_free(C->p);
+    C->p = reinterpret_cast<int64_t *>(hp.release());
+    C->h = reinterpret_cast<int64_t *>(h.release());
+    C->nvec = nonempty;
+    C->sparsity = GBA_HYPERSPARSE;
+    return GBA_SUCCESS;
+}
+
 // --------------------------------------------------------------- transpose --
 __global__ void __launch_bounds__(256)
 transpose_count_kernel(int64_t anz, const int64_t *__restrict__ Ai, unsigned long long *__restrict__ cnt) {

@@ -322,7 +322,6 @@ static bool shim_download (shim_operand *c, gba_matrix *dev)
     if (GxB_Global_Option_get_FUNCTION (GxB_MALLOC_FUNCTION, (void **) &lib_malloc) != GrB_SUCCESS || lib_malloc == NULL) return (false) ;
     if (GxB_Global_Option_get_FUNCTION (GxB_FREE_FUNCTION, (void **) &lib_free) != GrB_SUCCESS || lib_free == NULL) return (false) ;
     if (dev->nzombies > 0 && gba_matrix_wait (dev) != GBA_SUCCESS) return (false) ;     /* a packed matrix has no zombies */
-    if (dev->sparsity == GBA_HYPERSPARSE) return (false) ;
     gba_matrix h = (*dev) ;
     h.mem = GBA_MEM_HOST ; h.p = NULL ; h.h = NULL ; h.i = NULL ; h.x = NULL ; h.b = NULL ;
     size_t pb, hb, ib, xb, bb ;
@@ -331,8 +330,9 @@ static bool shim_download (shim_operand *c, gba_matrix *dev)
     void **dst [5] = {(void **) &(h.p), (void **) &(h.h), (void **) &(h.i), &(h.x), (void **) &(h.b)} ;
     const size_t need [5] = {pb, hb, ib, xb, bb} ;                          /* bytes to copy */
     size_t nb [5] ;                                                         /* bytes to allocate: pack wants non-NULL arrays */
-    const bool sparse = (dev->sparsity == GBA_SPARSE) ;
-    const bool wanted [5] = {sparse, false, sparse, true, dev->sparsity == GBA_BITMAP} ;
+    const bool hyper = (dev->sparsity == GBA_HYPERSPARSE) ;                 /* a C that came in hypersparse comes back so */
+    const bool sparse = (dev->sparsity == GBA_SPARSE) || hyper ;
+    const bool wanted [5] = {sparse, hyper, sparse, true, dev->sparsity == GBA_BITMAP} ;
     bool ok = true ;
     for (int k = 0 ; k < 5 ; k++)
     {
@@ -344,7 +344,7 @@ static bool shim_download (shim_operand *c, gba_matrix *dev)
     }
     if (!ok)
     {
-        lib_free (h.p) ; lib_free (h.i) ; lib_free (h.x) ; lib_free (h.b) ;
+        lib_free (h.p) ; lib_free (h.h) ; lib_free (h.i) ; lib_free (h.x) ; lib_free (h.b) ;
         return (false) ;
     }
     /* the old host arrays of C are not needed any more */
@@ -353,7 +353,7 @@ static bool shim_download (shim_operand *c, gba_matrix *dev)
     lib_free (old->h) ; lib_free (old->i) ; lib_free (old->x) ; lib_free (old->b) ;
     const bool is_vector = (c->w != NULL) ;
     c->v = h ;
-    c->p_size = nb [0] ; c->h_size = 0 ; c->i_size = nb [2] ; c->x_size = nb [3] ; c->b_size = nb [4] ;
+    c->p_size = nb [0] ; c->h_size = nb [1] ; c->i_size = nb [2] ; c->x_size = nb [3] ; c->b_size = nb [4] ;
     if (is_vector && h.sparsity == GBA_SPARSE)
     {
         int64_t nv = h.p [1] ;                                              /* Vector_pack_CSC takes nvals, not p */

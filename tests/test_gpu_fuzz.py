@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from graphblas_amd import Matrix, Type, GrbError, Info
+from graphblas_amd import Matrix, Type, Sparsity, GrbError, Info
 from graphblas_amd.binding import NP_TYPES
 from oracle import oracle
 from util import assert_dense_same
@@ -181,3 +181,7 @@ def _check(gba, seed, sr, A, B, C0, M, accum, desc, vector):
     p, v = oracle.mxm_spec(C0, M, accum, sr, A, B, desc)
     got = dC.to_host()
     assert_dense_same(got, p, v, exact=True, what=what)          # ANY_PAIR yields 1 everywhere: values are pinned too
+    if C0.sparsity == Sparsity.HYPERSPARSE and got.sparsity != Sparsity.BITMAP:
+        # a hypersparse C stays hypersparse: h lists exactly the non-empty vectors, in order
+        assert got.sparsity == Sparsity.HYPERSPARSE, what
+        assert np.all(np.diff(got.p) > 0) and np.all(np.diff(got.h) > 0), what
