@@ -176,7 +176,7 @@ gba_info dev_count_ones(const int8_t *b, int64_t n, int64_t *out_host);
 // method drivers (same contracts as the extern "C" entry points, operands on device)
 gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
                 const gba_matrix *A, const gba_matrix *B, const Canon &c,
-                int axb_method, int do_sort, bool *mask_applied, gba_report *rep);
+                int axb_method, int do_sort, bool *mask_applied, gba_report *rep, bool may_discard_mask = false);
 gba_info saxpy3_flopcount(int64_t *Mwork, int64_t *Bflops, const gba_matrix *M, bool Mask_comp,
                           const gba_matrix *A, const gba_matrix *B);
 gba_info dot3(gba_matrix *C, const gba_matrix *M, bool Mask_struct, const gba_matrix *A,

@@ -703,7 +703,7 @@ static gba_info run_saxpy(gba_matrix *T, const Call &k, const gba_matrix *C_in, 
         ex.rep.method = GBA_METHOD_SAXPY3;
         if (select_only) { ex.mask_applied = (M != nullptr); return GBA_SUCCESS; }
         gba_info info = (is_sparse(A) && is_sparse(B))
-            ? saxpy3(T, M, k.Mask_comp, k.Mask_struct, A, B, c, k.AxB_method, k.do_sort, &ex.mask_applied, &ex.rep)
+            ? saxpy3(T, M, k.Mask_comp, k.Mask_struct, A, B, c, k.AxB_method, k.do_sort, &ex.mask_applied, &ex.rep, true)
             : general_saxpy3(T, k, M, A, false, B, c, ex);
         if (info == GBA_NO_VALUE) {
             // mask discarded: redo the analysis without it (Source/GB_AxB_saxpy.c:212-225)

@@ -813,6 +813,30 @@ team_select_kernel(int64_t nvec, const int64_t *__restrict__ vflops, int64_t min
     }
 }
 
+// out[0] = multiply-adds of the product, out[1] = entries of M in the vectors that B fills
+__global__ void __launch_bounds__(256)
+mask_work_kernel(int64_t nvec, const int64_t *__restrict__ Bp, const int64_t *__restrict__ Mp,
+                 const int64_t *__restrict__ vflops, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long part[2][4];
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long f = 0, m = 0;
+    for (; j < nvec; j += stride) {
+        f += (unsigned long long)vflops[j];
+        if (Bp[j + 1] > Bp[j]) m += (unsigned long long)(Mp[j + 1] - Mp[j]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { f += __shfl_down(f, d, 64); m += __shfl_down(m, d, 64); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = f; part[1][threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        f = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        m = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        if (f) atomicAdd(&out[0], f);
+        if (m) atomicAdd(&out[1], m);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 zero_listed_kernel(int n, const int64_t *__restrict__ list, int64_t *__restrict__ work) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2026,7 +2050,7 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
 
 gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
                 const gba_matrix *A, const gba_matrix *B, const Canon &c,
-                int axb_method, int do_sort, bool *mask_applied, gba_report *rep) {
+                int axb_method, int do_sort, bool *mask_applied, gba_report *rep, bool may_discard_mask) {
     (void)axb_method;
     GBA_OK(require_init());
     if (!is_sparse(A) || !is_sparse(B))
@@ -2053,6 +2077,24 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     // bound on nnz C(:,j) whatever the mask does, which is what sizes the hash tables.
     DevBuf vflops; GBA_OK(vflops.alloc((size_t)(nvec + 1) * 8));
     GBA_OK(saxpy3_flopcount(nullptr, vflops.as<int64_t>(), nullptr, false, A, B));
+    // A sparse mask with far more entries than the product has multiply-adds costs more to scatter than it saves:
+    // the caller then multiplies without it and applies it in the write-back.  The reference's rule
+    // (Source/GB_AxB_saxpy3_slice_balanced.c:22, 309-403): discard when flops < 0.01 * (entries of M in the vectors
+    // that B fills).
+    if (may_discard_mask && M && is_sparse(M) && nvec > 0) {
+        DevBuf w; GBA_OK(w.alloc(16));
+        GBA_HIP(hipMemsetAsync(w.p, 0, 16, st));
+        int64_t blocks = ceil_div(nvec, 256); if (blocks > 512) blocks = 512;
+        hipLaunchKernelGGL(mask_work_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, B->p, M->p, vflops.as<int64_t>(),
+                           w.as<unsigned long long>());
+        unsigned long long hw[2] = {0, 0};
+        GBA_HIP(hipMemcpyAsync(hw, w.p, 16, hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipStreamSynchronize(st));
+        if ((double)hw[0] < 0.01 * (double)hw[1]) {
+            if (mask_applied) *mask_applied = false;
+            return GBA_NO_VALUE;
+        }
+    }
     // a few very heavy vectors: the whole grid works on each of them (team kernels)
     DevBuf team_list, team_Hx, team_Hf, symwork;
     const int64_t *symflops = vflops.as<int64_t>();
@@ -2098,9 +2140,21 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     // With sorted A the bitmap panel kernel also takes the vectors of the second block bin: it has no table to
     // clear per vector and records the numeric panel boundaries.
     // The panel kernels need sorted A and read its indices from a 32-bit copy made per call: a pass over all of
-    // A, which a product with a small B (a frontier against a large graph) must not pay for.  Such products
+    // A, which a small product (a short frontier against a large graph) must not pay for.  Such products
     // keep the memory-side accumulator kernels.
-    P.use_panels = !A->jumbled && B->nvals >= A->nvals / 32;
+    P.use_panels = !A->jumbled;
+    if (P.use_panels && B->nvals < A->nvals / 32 && nvec > 0) {
+        // few entries in B: the product may still be large (a block of hub rows); the multiply-adds decide
+        DevBuf w; GBA_OK(w.alloc(16));
+        GBA_HIP(hipMemsetAsync(w.p, 0, 16, st));
+        int64_t blocks = ceil_div(nvec, 256); if (blocks > 512) blocks = 512;
+        hipLaunchKernelGGL(mask_work_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, B->p, B->p, vflops.as<int64_t>(),
+                           w.as<unsigned long long>());
+        unsigned long long hw[2] = {0, 0};
+        GBA_HIP(hipMemcpyAsync(hw, w.p, 16, hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipStreamSynchronize(st));
+        P.use_panels = (double)hw[0] >= (double)A->nvals / 8;
+    }
     const int64_t sym_blk2_max = P.use_panels ? SYM_BLK1_MAX : SYM_BLK2_MAX;
     GBA_OK(build_bins(nvec, symflops, false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, sym_blk2_max}, &P.sym));
     P.vflops = vflops.as<int64_t>();

@@ -146,3 +146,28 @@ def test_sssp_rmat20_bellman_ford_bit_exact(gba):
         d = want
     assert it > 2 and np.isfinite(d).sum() > n // 4
     dA.free()
+
+
+def test_spmv_on_row_block_views(gba):
+    """The row block a rank owns is a view that keeps absolute offsets (p[0] != 0).  y_I += A(I,:)*x through the
+    tiled gather kernel and y' += x_I'*A(I,:) through the destination bins (more than 2^20 entries), with
+    small integer values so that every sum is exact, against scipy on the same rows."""
+    n, lo, hi = 1 << 17, 3_000, 125_000
+    A = gen.rmat(17, 16, seed=5, type=Type.FP64, values="int")            # CSR
+    S = A.to_scipy()[lo:hi]
+    assert S.nnz > (1 << 20)
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 3, n).astype(np.float64)
+    xI = rng.integers(0, 3, hi - lo).astype(np.float64)
+    dA = A.to_device()
+    blk = dA.row_slice(lo, hi)
+    dx, dxI = Matrix.full_vector(x).to_device(), Matrix.full_vector(xI).to_device()
+    dy = Matrix.full_vector(np.ones(hi - lo)).to_device()
+    rep = g.mxv(dy, None, "PLUS_FP64", "PLUS_TIMES_FP64", blk, dx)
+    assert g.Method.NAMES[rep.method] == "dot4"
+    assert np.array_equal(dy.to_host().x, 1.0 + S @ x)
+    dz = Matrix.full_vector(np.ones(n)).to_device()
+    rep = g.vxm(dz, None, "PLUS_FP64", "PLUS_TIMES_FP64", dxI, blk)
+    assert g.Method.NAMES[rep.method] == "saxpy4"
+    assert np.array_equal(dz.to_host().x, 1.0 + S.T @ xI)
+    _free(dA, dx, dxI, dy, dz)

@@ -394,3 +394,23 @@ def test_iso_valued_products_come_back_iso(gba, sr, t, b_iso, want_iso):
     assert_dense_same(got, p, v, exact=True, what=sr)
     for d in (dA, dB, dC):
         d.free()
+
+
+@pytest.mark.parametrize("desc", ["", "S", "C", "RS"])
+def test_costly_sparse_mask_is_discarded_and_applied_afterwards(gba, desc):
+    """A product of a few dozen multiply-adds under a sparse mask of thousands of entries: the reference drops
+    the mask from the multiply (flops < 0.01 * mask work, Source/GB_AxB_saxpy3_slice_balanced.c:22,309-403) and
+    applies it in the write-back; the result is the same, the report says the mask was not applied."""
+    n = 600
+    A, B = _rand(n, n, 0.0004, 41), _rand(n, n, 0.0004, 42)
+    A = Matrix.from_scipy((A.to_scipy() + sp.diags((np.arange(n) % 7 == 0).astype(np.float64))).tocsr(), type=Type.FP64)
+    B = Matrix.from_scipy((B.to_scipy() + sp.diags((np.arange(n) % 5 == 0).astype(np.float64))).tocsr(), type=Type.FP64)
+    M = _rand(n, n, 0.9, 43, t=Type.INT8, lo=0, hi=2)
+    C0 = _rand(n, n, 0.01, 44)
+    dA, dB, dM, dC = A.to_device(), B.to_device(), M.to_device(), C0.to_device()
+    rep = gba.mxm(dC, dM, None, "PLUS_TIMES_FP64", dA, dB, desc)
+    assert Method.NAMES[rep.method] == "saxpy3" and not rep.mask_applied
+    p, v = oracle.mxm_spec(C0, M, None, "PLUS_TIMES_FP64", A, B, desc)
+    assert_dense_same(dC.to_host(), p, v, exact=True, what=desc)
+    for d in (dA, dB, dM, dC):
+        d.free()
