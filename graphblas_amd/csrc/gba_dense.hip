@@ -536,7 +536,7 @@ bin_count_kernel(int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *_
                  int64_t nwg, int64_t *__restrict__ table) {
     constexpr int BIN_TILE = BIN_THREADS * BIN_ITEMS;
     extern __shared__ int bin_dyn[];
-    int *h = bin_dyn;                                         // h[b * BIN_COUNT_TILES + t]
+    int *h = bin_dyn;                                         // h[t * nb + b]: neighbouring bins in neighbouring banks
     const int tid = threadIdx.x;
     const int64_t wg0 = (int64_t)blockIdx.x * BIN_COUNT_TILES;
     const int64_t p0 = Ap[0], pN = Ap[nvecA];
@@ -553,12 +553,12 @@ bin_count_kernel(int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *_
             k[it] = (p < pN) ? __builtin_nontemporal_load(&Ai_lo[2 * p]) : -1;
         }
 #pragma unroll
-        for (int it = 0; it < BIN_ITEMS; it++) if (k[it] >= 0) atomicAdd(&h[(k[it] >> shift) * BIN_COUNT_TILES + t], 1);
+        for (int it = 0; it < BIN_ITEMS; it++) if (k[it] >= 0) atomicAdd(&h[t * nb + (k[it] >> shift)], 1);
     }
     __syncthreads();
     for (int q = tid; q < nb * BIN_COUNT_TILES; q += BIN_THREADS) {
         const int b = q / BIN_COUNT_TILES, t = q - b * BIN_COUNT_TILES;
-        if (wg0 + t < nwg) table[(int64_t)b * nwg + wg0 + t] = h[q];      // bin-major
+        if (wg0 + t < nwg) table[(int64_t)b * nwg + wg0 + t] = h[t * nb + b];      // bin-major
     }
 }
 

@@ -225,10 +225,15 @@ void     gba_matrix_free_content(gba_matrix *A);
  * input) and its sparsity/jumbled/nzombies fields describe the result, exactly
  * as GB_mxm leaves its C (Source/GB_mxm.c:149-221).
  * Operands and C of another built-in real type than the semiring's are cast
- * (Source/GB_casting.h rules); hypersparse A, B, M and C are accepted and C
- * comes back sparse.
+ * (Source/GB_casting.h rules); hypersparse A, B, M and C are accepted; a C
+ * that is hypersparse on entry is hypersparse on return, any other sparse
+ * result stays sparse.  A product that replaces C and is iso-valued by the
+ * rule of Source/GB_AxB_iso.c comes back with iso = true and one value in x.
+ * A sparse mask far costlier than the product is left out of the multiply and
+ * applied in the write-back (Source/GB_AxB_saxpy3_slice_balanced.c:309-403);
+ * report->mask_applied tells which happened.
  * Returns GBA_NOT_IMPLEMENTED for valid calls outside the device path
- * (complex types, user-defined ops -- see gba_mxm_udt --, iso-valued C, ...):
+ * (complex types, user-defined ops -- see gba_mxm_udt --, ...):
  * the caller keeps the CPU library for those, like the GB_cuda_*_branch test
  * in Source/GB_AxB_dot.c:189-197. */
 gba_info gba_mxm(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
