@@ -178,7 +178,8 @@ def test_saxpy4_in_place(gba, sr, t, bkind):
 
 @pytest.mark.parametrize("sr,t", [("PLUS_TIMES_FP32", Type.FP32), ("PLUS_TIMES_FP64", Type.FP64), ("MIN_PLUS_FP64", Type.FP64),
                                   ("PLUS_TIMES_INT64", Type.INT64), ("BXOR_BAND_UINT32", Type.UINT32),
-                                  ("MAX_SECOND_INT32", Type.INT32)])
+                                  ("MAX_SECOND_INT32", Type.INT32), ("PLUS_PAIR_INT64", Type.INT64), ("MIN_PLUS_FP32", Type.FP32),
+                                  ("PLUS_FIRST_FP64", Type.FP64), ("TIMES_SECOND_UINT64", Type.UINT64)])
 def test_saxpy4_large_goes_through_destination_bins(gba, sr, t):
     """More than 2^20 entries and B full: products are binned by destination and summed in LDS panels.
     The matrix has a vector longer than a tile, a run of empty vectors, a destination hit 30000 times,
@@ -240,6 +241,26 @@ def test_saxbit(gba, sr, t, mask):
     out, _ = gba.AxB_saxbit(dM, comp, True, dA, dB, sr)
     assert_same(out.to_host(), oracle.saxbit(M, comp, True, A, B, sr), exact=True, what=sr)
     _free(dA, dB, dM, out)
+
+
+@pytest.mark.parametrize("nvec", [1, 8, 9])
+def test_saxpy4_bins_with_iso_A_and_several_vectors(gba, nvec):
+    """A iso (one stored value), 1, 8 and 9 dense vectors (nine is beyond what the bins take: the tile kernel
+    runs), a destination count that is not a multiple of the bin width."""
+    rng = np.random.default_rng(27)
+    n, inner = 70_001, 60_000
+    S = sp.random(n, inner, density=1_200_000 / (n * inner), random_state=rng, format="csc")
+    S.data[:] = 2.0
+    assert S.nnz > (1 << 20)
+    A0 = Matrix.from_scipy(S, type=Type.FP64, by_row=False)
+    A = Matrix(A0.vlen, A0.vdim, Type.FP64, Sparsity.SPARSE, True, p=A0.p, i=A0.i, x=np.array([2.0]), iso=True, nvals=A0.nvals)
+    B = Matrix.dense(rng.integers(0, 3, (inner, nvec)).astype(np.float64), by_row=False)
+    C0 = Matrix.dense(rng.integers(0, 3, (n, nvec)).astype(np.float64), by_row=False)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    assert gba.AxB_saxpy4(dC, dA, dB, "PLUS_TIMES_FP64") is not None
+    want = C0.x.reshape(nvec, n).T + S @ B.x.reshape(nvec, inner).T
+    assert np.array_equal(dC.to_host().x.reshape(nvec, n).T, want)
+    _free(dA, dB, dC)
 
 
 def _hub_matrix(n, inner, t, seed):
