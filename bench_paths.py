@@ -5,6 +5,7 @@
             y' += x'*A (saxpy4, scatter) -- PLUS_TIMES_FP32 through gba_mxv / gba_vxm
   tricount  L = tril(A|A', -1), C<L,struct> = L*L' PLUS_PAIR_INT64 through gba_mxm (dot3), sum(C)
   bfs       level-synchronous BFS from the highest-degree vertex, one masked gba_vxm per level
+  sssp      Bellman-Ford from the highest-degree vertex, one gba_vxm (MIN_PLUS_FP64, MIN accumulator) per iteration
 
 Prints one JSON line per measurement: device time per call (HIP events on the library stream, from
 the call's report), algorithmic bytes per call and the HBM rate they give.
@@ -164,13 +165,49 @@ def bfs(args):
          GTEPS=round(nnz / total_ms / 1e6, 3), levels=levels)
 
 
+def sssp(args):
+    """Bellman-Ford, every iteration d = min(d, d min.+ A) as one gba_vxm with MIN_PLUS_FP64 and the MIN accumulator
+    (C full, in place: saxpy4), from the highest-degree vertex until nothing changes."""
+    import graphblas_amd as g
+    from graphblas_amd import gen, Matrix, Type
+    A = gen.rmat(args.scale, 16, seed=42, type=Type.FP64)            # CSR, weights uniform in (0, 1]
+    n, nnz = A.nrows, A.nvals
+    src = int(np.argmax(np.diff(A.p)))
+    dA = A.to_device()
+    alg = nnz * 16 + (n + 1) * 8 + 2 * n * 8
+    for trial in range(2):                                   # the second traversal is the warm one
+        d = np.full(n, np.inf); d[src] = 0.0
+        its = []
+        for it in range(64):
+            dcur = Matrix.full_vector(d).to_device()
+            dnew = Matrix.full_vector(d.copy()).to_device()
+            g.sync()
+            t0 = time.perf_counter()
+            rep = g.vxm(dnew, None, "MIN_FP64", "MIN_PLUS_FP64", dcur, dA)
+            g.sync()
+            ms = (time.perf_counter() - t0) * 1e3
+            got = dnew.to_host().x
+            dcur.free(); dnew.free()
+            its.append(dict(iteration=it, method=g.Method.NAMES[rep.method], ms=round(ms, 3), device_ms=round(rep.kernel_ms, 3),
+                            reached=int(np.isfinite(got).sum())))
+            if np.array_equal(got, d):
+                break
+            d = got
+    dA.free()
+    total = sum(x["ms"] for x in its)
+    emit(case="SSSP Bellman-Ford, MIN_PLUS_FP64 with MIN accumulator", workload=f"RMAT-{args.scale} ef=16 seed=42, weights uniform (0,1]",
+         n=n, nnz=nnz, source=src, iterations=len(its), total_ms=round(total, 2), ms_per_iteration=round(total / len(its), 3),
+         algorithmic_bytes_per_iteration=alg, achieved=round(alg / (total / len(its) * 1e-3) / 1e9, 1), unit="GB/s", peak=HBM_PEAK_GBS,
+         reached=its[-1]["reached"], per_iteration=its)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["spmv", "tricount", "bfs"])
+    ap.add_argument("what", choices=["spmv", "tricount", "bfs", "sssp"])
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--type", choices=["fp32", "fp64"], default="fp32", help="spmv value type")
     a = ap.parse_args()
     import graphblas_amd as g
     g.init(0)
-    {"spmv": spmv, "tricount": tricount, "bfs": bfs}[a.what](a)
+    {"spmv": spmv, "tricount": tricount, "bfs": bfs, "sssp": sssp}[a.what](a)
