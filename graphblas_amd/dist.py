@@ -168,3 +168,19 @@ class FrontierExchange:
             t.copy_(h)
         else:
             self.dist.all_reduce(t, op=op)
+
+
+class ScalarReduce:
+    """The reduction that ends a sharded masked dot product: for C<L> = L*L' (triangle counting, dot3) the mask is
+    cut into row blocks, every rank multiplies C(I,:)<L(I,:)> = L(I,:)*L' against the whole of L (replicated, or
+    gathered from the blocks with RowBlockExchange) and only the per-rank sums of C travel."""
+
+    def __init__(self, dist, torch, world, device):
+        self.dist, self.torch, self.world, self.device = dist, torch, world, device
+
+    def sum_int64(self, value):
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64,
+                              device=self.device if self.world > 1 and self.dist.get_backend() == "nccl" else "cpu")
+        if self.world > 1:
+            self.dist.all_reduce(t)
+        return int(t.item())

@@ -182,3 +182,48 @@ def test_two_ranks_reproduce_spmv_iterations_and_bfs_levels(tmp_path):
         for q in range(world):
             wb[gp[q]:gp[q + 1]:3] = 1
         assert np.array_equal(got["b"], wb)
+
+
+def _worker_triangles(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from graphblas_amd import gen, Matrix, Type
+    from graphblas_amd.dist import ScalarReduce
+    from oracle import oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A = gen.rmat(9, 8, seed=42, type=Type.INT64, values="ones", symmetric=True, drop_diagonal=True)
+    L = gen.tril_strict(A)                                        # CSR
+    # rows of the mask split by the work of the masked dot products: sum over L(i,j) of |L(i,:)| + |L(j,:)|
+    deg = np.diff(L.p)
+    rows = np.repeat(np.arange(L.nrows), deg)
+    work = np.bincount(rows, weights=(deg[rows] + deg[L.i]).astype(np.float64), minlength=L.nrows)
+    prefix = np.concatenate([[0], np.cumsum(work)])
+    part = split_by_flops(prefix, 0, L.nrows, world)
+    lo, hi = part[rank], part[rank + 1]
+    e0, e1 = int(L.p[lo]), int(L.p[hi])
+    p = (L.p[lo:hi + 1] - L.p[lo]).astype(np.int64)
+    Lblk = Matrix(L.vlen, hi - lo, Type.INT64, L.sparsity, L.is_csc, p=p, i=L.i[e0:e1], x=L.x[e0:e1])
+    # C(I,:)<L(I,:)> = L(I,:) * L'.  In the method's terms (vectors = rows): C_I<M> = A_I' B_I with A_I = L, B_I = M = L(I,:)
+    C = oracle.dot3(Lblk, True, L, Lblk, "PLUS_PAIR_INT64")
+    mine = int(C.x[C.i >= 0].sum())
+    total = ScalarReduce(dist, torch, world, torch.device("cpu")).sum_int64(mine)
+    np.savez(os.path.join(outdir, f"t{rank}.npz"), mine=mine, total=total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_count_the_triangles_of_the_whole_graph(tmp_path):
+    """dot3 sharded by row blocks of the mask with L replicated: the per-rank sums add up to the one-process count."""
+    import torch.multiprocessing as mp
+    from graphblas_amd import gen, Type
+    from oracle import oracle
+    world, port = 2, 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_triangles, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    A = gen.rmat(9, 8, seed=42, type=Type.INT64, values="ones", symmetric=True, drop_diagonal=True)
+    L = gen.tril_strict(A)
+    C = oracle.dot3(L, True, L, L, "PLUS_PAIR_INT64")
+    want = int(C.x[C.i >= 0].sum())
+    got = [np.load(tmp_path / f"t{r}.npz") for r in range(world)]
+    assert all(int(g["total"]) == want for g in got)
+    assert sum(int(g["mine"]) for g in got) == want and all(int(g["mine"]) > 0 for g in got)
