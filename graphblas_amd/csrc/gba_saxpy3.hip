@@ -975,6 +975,7 @@ static constexpr int NUM_PANEL_SLOTS = 8192;
 static constexpr int NUM_PANEL_TARGET = 3000;                         // distinct indices aimed at per panel (no boundaries known)
 static constexpr int NUM_PANEL_FIT = 6144;                            // entries between two recorded boundaries
 static constexpr int SYM_WORDS_PER_THREAD = SYM_PANEL_WORDS / PANEL_THREADS;
+static constexpr int SYM_STAGE = PANEL_SEGCAP;                        // (word, bits) pairs that fit the run queue's position array
 static constexpr int PANEL_PROBE_LIMIT = 48;
 static constexpr int64_t PANEL_INF = (int64_t)1 << 62;
 static constexpr int PANEL_SCRATCH_ARRAYS = 5;
@@ -999,6 +1000,7 @@ struct PanelSegs {
     unsigned long long where[PANEL_SEGCAP];   // position of the run in A (high 40 bits) | neighbour ordinal (low 24)
     uint32_t off[PANEL_SEGCAP];               // run length; exclusive prefix sum once the runs are expanded
     uint32_t wsum[PANEL_THREADS / 64];
+    uint64_t wsum2[PANEL_THREADS / 64];        // the symbolic sweep's packed sums (entries | non-empty words)
     unsigned long long wmask[PANEL_THREADS / 64][PANEL_UNROLL_MAX];   // per wave: products of the window at which a run starts
     int nseg;
     uint32_t wnext;                           // next window of products to hand to a wave
@@ -1018,6 +1020,13 @@ struct PanelCursors {
         int64_t *b = nv_in; nv_in = nv_out; nv_out = b;
     }
 };
+
+// a value every lane of the wave holds alike, moved to scalar registers (lane 0's copy)
+__device__ inline int64_t uniform_i64(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
 
 // first p in [lo,hi) with X[p] >= target (hi if none): gallop from lo, then bisect
 __device__ inline int64_t first_ge(const int32_t *__restrict__ X, int64_t lo, int64_t hi, int64_t target) {
@@ -1109,6 +1118,31 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
                 placed = true;
             }
             const uint32_t wend = w0 + WIN;
+            // No run starts inside the window (the common case when runs are long: symbolic panels): every
+            // product belongs to run sb, its position is the run's start plus the lane -- one uniform base,
+            // no marks, no per-product lookup.
+            const uint32_t nxt = (sb + 1 < n) ? S->off[sb + 1] : ~0u;
+            if (nxt >= wend) {
+                const unsigned long long w = S->where[sb];
+                const uint32_t rel = w0 - S->off[sb];
+                const int64_t a0 = uniform_i64((int64_t)(w >> PANEL_T_BITS) + (int64_t)rel);
+                const int64_t pBu = uniform_i64(pB0 + (int64_t)(w & (unsigned long long)(PANEL_MAX_DEG - 1)));
+                const int32_t *__restrict__ Arun = Ai + a0;
+                uint32_t xo[PANEL_UNROLL];
+#pragma unroll
+                for (int u = 0; u < PANEL_UNROLL; u++) {
+                    const uint32_t x = (uint32_t)u * 64 + (uint32_t)lane;
+                    const bool inside = w0 + x < T;
+                    ok[u] = inside && real;
+                    xo[u] = inside ? x : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < PANEL_UNROLL; u++) ii[u] = Arun[xo[u]];
+#pragma unroll
+                for (int u = 0; u < PANEL_UNROLL; u++) raw[u] = load(ii[u], a0 + (int64_t)xo[u], pBu);
+                if (!dynamic) { sb += (nxt == wend) ? 1 : 0; win = real ? win + 1 : win_end; }
+                return real;
+            }
             if (lane < PANEL_UNROLL) wm[lane] = 0ull;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             bool edge = false;                          // a run starts exactly at the next window
@@ -1446,6 +1480,24 @@ bounds_room_kernel(int64_t nvec, const int64_t *__restrict__ vflops, int64_t cvl
     }
 }
 
+// proom[j] = room for the pattern of C(:,j) in units bounded by its multiply-adds and by `most` (0 for vectors
+// the panel kernel does not count)
+__global__ void __launch_bounds__(256)
+pattern_room_kernel(int64_t nvec, const int64_t *__restrict__ vflops, int64_t most, int64_t panel_min_flops,
+                    int64_t *__restrict__ proom) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; idx <= nvec; idx += stride) {
+        int64_t r = 0;
+        if (idx < nvec && vflops[idx] > panel_min_flops) r = (vflops[idx] < most) ? vflops[idx] : most;
+        proom[idx] = r;
+    }
+}
+
+#ifdef GBA_PANEL_TICKS
+__device__ unsigned long long g_sym_ticks[8];      // stopwatch slots of the symbolic panel kernel, summed over workgroups
+#endif
+
 // The symbolic sweep also records, for the numeric sweep, where the vector's
 // pattern crosses every multiple of NUM_PANEL_FIT entries: bounds[bstart[j] + m - 1]
 // is one past the index of the (m * NUM_PANEL_FIT)-th entry of C(:,j).  Panels cut
@@ -1455,7 +1507,8 @@ template <bool MASKED>
 __global__ void __launch_bounds__(PANEL_THREADS)
 sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int64_t cvlen,
                  int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
-                 int64_t *__restrict__ cnt, const int64_t *__restrict__ bstart, int64_t *__restrict__ bounds) {
+                 int64_t *__restrict__ cnt, const int64_t *__restrict__ bstart, int64_t *__restrict__ bounds,
+                 const int64_t *__restrict__ pstart, uint2 *__restrict__ pwords, int64_t *__restrict__ wbounds) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *bm = reinterpret_cast<uint32_t *>(smem);
     __shared__ PanelSegs Q;
@@ -1465,6 +1518,7 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
     if (tid == 0) { Q.nseg = 0; Q.overflow = 0; }
 #ifdef GBA_PANEL_TICKS
     if (tid == 0) for (int q = 0; q < 8; q++) Q.tk[q] = 0;
+    const unsigned long long tkk = wall_clock64();
 #endif
     PanelCursors pc(scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg, maxdeg);
     const int64_t npanels = (cvlen + SYM_PANEL_WIDTH - 1) / SYM_PANEL_WIDTH;
@@ -1476,7 +1530,9 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
         const int64_t j = list[li];
         const int64_t pB0 = B.p[j], deg = B.p[j + 1] - pB0;
         int64_t *jb = bounds + bstart[j];
-        int64_t seen = 0;                                   // entries of C(:,j) below the current panel
+        uint2 *pw = pwords ? pwords + pstart[j] : nullptr;  // where the non-empty bitmap words of C(:,j) are written, in index order
+        int64_t *jw = pwords ? wbounds + bstart[j] : nullptr;   // and where the word of every boundary stands in that list
+        int64_t seen = 0, wseen = 0;                        // entries / non-empty words of C(:,j) below the current panel
         for (int64_t p = 0; p < npanels; p++) {
             const int64_t base = p * SYM_PANEL_WIDTH;
             const int64_t pend = (p == npanels - 1) ? PANEL_INF : base + SYM_PANEL_WIDTH;
@@ -1493,22 +1549,35 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                         atomicOr(&bm[o >> 5], 1u << (o & 31));
                     }
                 });
-            // count in index order: each thread owns SYM_WORDS_PER_THREAD consecutive words
-            int mine = 0;
+            // count in index order: each thread owns SYM_WORDS_PER_THREAD consecutive words, read once with 16-byte
+            // LDS loads (conflict-free at this stride); the packed sum carries the entries (low 20 bits: a panel has
+            // at most 2^19.6) and the non-empty words (above) of the slice
             const int w0 = tid * SYM_WORDS_PER_THREAD;
-            for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) mine += __builtin_popcount(bm[w0 + q]);
-            int incl = mine;
+            uint4 *b4 = reinterpret_cast<uint4 *>(bm + w0);
+            uint64_t both = 0;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
-            if (lane == 63) Q.wsum[wv] = (uint32_t)incl;
+            for (int q = 0; q < SYM_WORDS_PER_THREAD / 4; q++) {
+                const uint4 v = b4[q];
+                both += (uint64_t)(__builtin_popcount(v.x) + __builtin_popcount(v.y) + __builtin_popcount(v.z) + __builtin_popcount(v.w))
+                      + ((uint64_t)((v.x != 0u) + (v.y != 0u) + (v.z != 0u) + (v.w != 0u)) << 20);
+            }
+            const int mine = (int)(both & 0xfffffu), nzc = (int)(both >> 20);
+            uint64_t incl2 = both;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint64_t u = __shfl_up((unsigned long long)incl2, d, 64); if (lane >= d) incl2 += u; }
+            if (lane == 63) Q.wsum2[wv] = incl2;
             __syncthreads();
-            int woff = 0, total = 0;
+            uint64_t woff2 = 0, total2 = 0;
 #pragma unroll
-            for (int q = 0; q < PANEL_THREADS / 64; q++) { const int w = (int)Q.wsum[q]; if (q < wv) woff += w; total += w; }
-            const int64_t lo = seen + woff + incl - mine;   // entries before this thread's slice
+            for (int q = 0; q < PANEL_THREADS / 64; q++) { const uint64_t w = Q.wsum2[q]; if (q < wv) woff2 += w; total2 += w; }
+            const uint64_t excl2 = woff2 + incl2 - both;
+            const int total = (int)(total2 & 0xfffffu), nztotal = (int)(total2 >> 20);
+            const int nzlo = (int)(excl2 >> 20);                // non-empty words of the panel before this thread's slice
+            const int64_t lo = seen + (int64_t)(excl2 & 0xfffffu);   // entries before this thread's slice
             const int64_t m = lo / NUM_PANEL_FIT + 1;       // the next multiple to be crossed
             if (m * NUM_PANEL_FIT <= lo + mine) {
                 int r = (int)(m * NUM_PANEL_FIT - lo);      // the r-th set bit of the slice, 1-based
+                int nzb = 0;                                // non-empty words of the slice before the one that holds it
                 for (int q = 0; q < SYM_WORDS_PER_THREAD && r > 0; q++) {
                     const uint32_t xq = bm[w0 + q];
                     const int pcq = __builtin_popcount(xq);
@@ -1516,21 +1585,50 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                         uint32_t y = xq;
                         for (int z = 1; z < r; z++) y &= y - 1;
                         jb[m - 1] = base + (int64_t)(w0 + q) * 32 + __builtin_ctz(y) + 1;
+                        if (jw) jw[m - 1] = wseen + nzlo + nzb;   // where that word stands in the vector's list of words
                         r = 0;
                     } else {
                         r -= pcq;
+                        nzb += (xq != 0u) ? 1 : 0;
                     }
                 }
             }
-            if (mine) for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) bm[w0 + q] = 0;   // own slice only: no barrier needed
+            // The pattern itself, for the numeric sweep that ranks instead of hashing: the non-empty words of the
+            // bitmap as (word number, bits) pairs in index order.  A thread's words follow those of the thread before,
+            // so the lanes of a wave write neighbouring places: one trip per word, whatever its bits, no staging.
+            if (pw) {
+                uint2 *out = pw + wseen + nzlo;
+                const uint32_t wid0 = (uint32_t)(base >> 5) + (uint32_t)w0;
+                if (nzc) {
+#pragma unroll
+                    for (int q = 0; q < SYM_WORDS_PER_THREAD / 4; q++) {
+                        const uint4 v = b4[q];
+                        if (v.x) *out++ = make_uint2(wid0 + 4u * q, v.x);
+                        if (v.y) *out++ = make_uint2(wid0 + 4u * q + 1u, v.y);
+                        if (v.z) *out++ = make_uint2(wid0 + 4u * q + 2u, v.z);
+                        if (v.w) *out++ = make_uint2(wid0 + 4u * q + 3u, v.w);
+                    }
+                }
+                wseen += nztotal;
+            }
+            if (mine) {                                     // own slice only: no barrier needed
+#pragma unroll
+                for (int q = 0; q < SYM_WORDS_PER_THREAD / 4; q++) b4[q] = make_uint4(0u, 0u, 0u, 0u);
+            }
             seen += total;
             const int more = Q.more;
             pc.swap();
             __syncthreads();
             if (!more) break;
         }
-        if (tid == 0) cnt[j] = seen;
+        if (tid == 0) {
+            cnt[j] = seen;
+            if (jw) jw[seen / NUM_PANEL_FIT] = wseen;       // (the slot after the last boundary) the length of the list
+        }
     }
+#ifdef GBA_PANEL_TICKS
+    if (tid == 0) { Q.tk[7] = wall_clock64() - tkk; for (int q = 0; q < 8; q++) atomicAdd(&g_sym_ticks[q], Q.tk[q]); }
+#endif
 }
 
 // A unit of work of the numeric panel kernel: the stretches [q0, q1) of C(:,j), where stretch q lies
@@ -1596,51 +1694,80 @@ panel_task_fill_kernel(int64_t nlist, const int64_t *__restrict__ list, const in
 __device__ inline uint32_t panel_hash(int32_t key) { return ((uint32_t)key * 0x9E3779B1u) >> 19; }
 static_assert(NUM_PANEL_SLOTS == (1 << 13), "panel_hash keeps the top 13 bits");
 
+// Ranked panels.  When the symbolic sweep wrote the pattern of C(:,j) down -- the non-empty words of its bitmap
+// as (word number, bits) pairs in index order, and where the word of every boundary stands in that list -- a
+// stretch between two boundaries that spans at most RANK_WORDS words needs no hashing.  Its pairs are read,
+// coalesced, ranked by a prefix sum of their popcounts, and laid into an LDS table with one entry per 32
+// indices of the panel's range: the bits present and the rank of the first of them.  Entry e of the panel owns
+// vals[e].  A product then costs one 8-byte LDS read, a popcount, the monoid's LDS atomic and a store of its
+// index: no probing, no compare-and-swap, nothing divergent.  Products whose index is not in the pattern
+// (masked out) find their bit clear and are dropped, so the mask is not consulted.  The panel leaves vals in
+// index order: Cx and Ci are straight copies.  Wider (sparser) stretches are hashed as before; the two table
+// layouts share the same LDS and are re-initialised when the kind of panel changes.
+static constexpr int RANK_WORDS = 4608;                               // 36 KiB of LDS
+static constexpr int RANK_PPT = 5;                                    // pairs per thread: a ranked stretch has at most RANK_WORDS + 1
+static_assert(RANK_PPT * PANEL_THREADS > RANK_WORDS, "all pairs of a ranked stretch are held at once");
+static_assert((int64_t)RANK_WORDS * 32 <= PANEL_MAX_WIDTH, "ranked panel too wide for 32-bit product offsets");
+
+template <class ACC> constexpr size_t num_panel_lds() {
+    constexpr size_t hashed = (size_t)NUM_PANEL_SLOTS * (sizeof(ACC) + 4);
+    constexpr size_t ranked = (size_t)NUM_PANEL_FIT * (sizeof(ACC) + 4) + (size_t)RANK_WORDS * 8;
+    return hashed > ranked ? hashed : ranked;
+}
+
 template <class S, bool MASKED>
 __global__ void __launch_bounds__(PANEL_THREADS)
 num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpView A, SpView B, MaskView M, int64_t cvlen,
                  int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
                  const int64_t *__restrict__ Cp, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx,
-                 const int64_t *__restrict__ bstart, const int64_t *__restrict__ bounds) {
+                 const int64_t *__restrict__ bstart, const int64_t *__restrict__ bounds,
+                 const int64_t *__restrict__ pstart, const uint2 *__restrict__ pwords, const int64_t *__restrict__ wbounds) {
     using Z = typename S::z_t; using ACC = typename S::acc_t;
     extern __shared__ __align__(16) unsigned char smem[];
     ACC *vals = reinterpret_cast<ACC *>(smem);
-    int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)NUM_PANEL_SLOTS * sizeof(ACC));
+    int32_t *keys = reinterpret_cast<int32_t *>(smem + (size_t)NUM_PANEL_SLOTS * sizeof(ACC));    // hashed layout
+    int32_t *ridx = reinterpret_cast<int32_t *>(smem + (size_t)NUM_PANEL_FIT * sizeof(ACC));      // ranked layout: index of entry e
+    uint2 *rk = reinterpret_cast<uint2 *>(smem + (size_t)NUM_PANEL_FIT * (sizeof(ACC) + 4));      //   and (bits, first rank) per 32 indices
     unsigned long long st_panels = 0, st_overflows = 0;     // next[1], next[2]: panels swept / redone (reporting)
-    unsigned long long st_direct = 0, st_dent = 0, st_hent = 0;   // next[11..13]: direct panels, entries by kind of panel
+    unsigned long long st_direct = 0, st_dent = 0, st_hent = 0;   // next[11..13]: direct or ranked panels, entries by kind of panel
     __shared__ PanelSegs Q;
     __shared__ int64_t row;
     __shared__ int out_cursor;
     const ACC ident = (ACC)sr.identity();
     const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
-    const int lane64 = threadIdx.x & 63;
+    const int tid = threadIdx.x, lane64 = tid & 63;
     PanelCursors pc(scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg, maxdeg);
-    for (int s = threadIdx.x; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
-    if (threadIdx.x == 0) Q.nseg = 0;
+    for (int s = tid; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
+    bool rank_layout = false;                               // which of the two layouts the LDS holds, clean
+    if (tid == 0) Q.nseg = 0;
 #ifdef GBA_PANEL_TICKS
-    if (threadIdx.x == 0) for (int q = 0; q < 8; q++) Q.tk[q] = 0;
+    if (tid == 0) for (int q = 0; q < 8; q++) Q.tk[q] = 0;
     const unsigned long long tkk = wall_clock64();
 #endif
     while (true) {
-        if (threadIdx.x == 0) row = (int64_t)atomicAdd(next, 1ull);
+        if (tid == 0) row = (int64_t)atomicAdd(next, 1ull);
         __syncthreads();
-        const int64_t li = row;
+        const int64_t li = uniform_i64(row);
         if (li >= nlist) break;
         const PanelTask task = tasks[li];
         const int64_t j = task.j;
         const int64_t pB0 = B.p[j], deg = B.p[j + 1] - pB0;
-        int64_t pC = Cp[j];
+        const int64_t pC0 = Cp[j];
+        int64_t pC = pC0;
         const int64_t cj = Cp[j + 1] - pC;
         int64_t base = 0, iend = PANEL_INF;
         int64_t width = (cj > 0) ? (cvlen * NUM_PANEL_TARGET) / cj : cvlen;
         if (width > 4096) width = 4096;                 // the low indices are the dense end of a power-law vector
         if (width < 1) width = 1;
         bool first = true;
-        // boundaries recorded by the symbolic sweep, if it was the panel kernel that counted this vector
+        // boundaries (and the pattern) recorded by the symbolic sweep, if it was the panel kernel that counted this vector
         const int64_t *jb = nullptr;
+        const uint2 *__restrict__ pw = nullptr;
+        const int64_t *jw = nullptr;
         int64_t nb = 0, mb = 0;
         if (bstart && bstart[j + 1] > bstart[j]) {
             jb = bounds + bstart[j]; nb = cj / NUM_PANEL_FIT;
+            if (pwords) { pw = pwords + pstart[j]; jw = wbounds + bstart[j]; }
             if (task.q0 > 0) { base = jb[task.q0 - 1]; pC += (int64_t)task.q0 * NUM_PANEL_FIT; mb = task.q0; }
             if (task.q1 <= nb) iend = jb[task.q1 - 1];
         }
@@ -1653,31 +1780,104 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                 width >>= shrink;
                 if (width < 1) width = 1;
             }
-            // a panel no wider than the table needs no hashing: slot = i - base, any number of entries fits
-            const bool direct = width <= NUM_PANEL_SLOTS;
-            int64_t lim = base + (direct ? NUM_PANEL_SLOTS : ((width < PANEL_MAX_WIDTH) ? width : PANEL_MAX_WIDTH));
+            // with the pattern on record a whole stretch that spans no more words than the rank table has is
+            // ranked; without it a panel no wider than the hash table is addressed directly (slot = i - base);
+            // everything else is hashed
+            bool ranked = false;
+            int64_t p0 = 0, np = 0;                     // the stretch's pairs: pw[p0 .. p0 + np)
+            if (pw && shrink == 0 && base == ((mb > 0) ? jb[mb - 1] : 0)
+                && ((base + width - 1) >> 5) - (base >> 5) < (int64_t)RANK_WORDS) {
+                p0 = (mb > 0) ? jw[mb - 1] : 0;
+                np = ((mb < nb) ? jw[mb] : jw[nb] - 1) - p0 + 1;
+                ranked = np >= 1 && np <= (int64_t)RANK_PPT * PANEL_THREADS;
+            }
+            const bool direct = !ranked && width <= NUM_PANEL_SLOTS;
+            int64_t lim = base + (ranked ? width : direct ? (int64_t)NUM_PANEL_SLOTS : ((width < PANEL_MAX_WIDTH) ? width : PANEL_MAX_WIDTH));
             if (lim > iend) lim = iend;
+            lim = uniform_i64(lim);
             const int64_t pend = (lim >= cvlen) ? PANEL_INF : lim;
-            if (threadIdx.x == 0) { Q.overflow = 0; Q.more = 0; out_cursor = 0; }
+            const int32_t base32 = (int32_t)base;
+            const uint32_t wbase32 = (uint32_t)(base >> 5);
+            if (tid == 0) { Q.overflow = 0; Q.more = 0; out_cursor = 0; }
             GBA_TICK(tkp0);
+            if (ranked != rank_layout) {                // uniform: the other layout takes over the shared part of the LDS
+                if (ranked) {
+                    for (int s = tid; s < RANK_WORDS; s += PANEL_THREADS) rk[s] = make_uint2(0u, 0u);
+                } else {
+                    for (int s = tid; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) keys[s] = HASH_EMPTY;
+                    for (int s = NUM_PANEL_FIT + tid; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) vals[s] = ident;
+                }
+                rank_layout = ranked;
+            }
+            // a ranked panel's pairs: read, trimmed to [base, lim) at both ends, their popcounts summed per wave
+            uint32_t pwid[RANK_PPT], pbit[RANK_PPT];
+            uint32_t incl = 0, mysum = 0;
+            if (ranked) {
+                const uint2 *__restrict__ pp = pw + p0;
+                const uint32_t widb = (uint32_t)(base >> 5), widl = (uint32_t)(lim >> 5);
+                const uint32_t lowcut = ~((1u << (uint32_t)(base & 31)) - 1u), highcut = (1u << (uint32_t)(lim & 31)) - 1u;
+#pragma unroll
+                for (int q = 0; q < RANK_PPT; q++) {
+                    const int el = tid * RANK_PPT + q;              // consecutive pairs per thread: one prefix sum ranks them
+                    uint2 w = make_uint2(0u, 0u);
+                    if (el < (int)np) w = pp[el];
+                    if (w.x == widb) w.y &= lowcut;
+                    if (w.x == widl) w.y &= highcut;                // (lim a multiple of 32: nothing of that word belongs here)
+                    if (w.x < widb || w.x > widl) w.y = 0u;         // (the list starts at the word of the last entry before base)
+                    pwid[q] = w.x - widb; pbit[q] = w.y;
+                    mysum += (uint32_t)__builtin_popcount(w.y);
+                }
+                incl = mysum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d, 64); if (lane64 >= d) incl += u; }
+                if (lane64 == 63) Q.wsum[tid >> 6] = incl;
+            }
             __syncthreads();
+            int rtotal = 0;
+            if (ranked) {
+                // the table: (bits, rank of the word's first index) per 32 indices of the panel's range
+                uint32_t woff = 0;
+#pragma unroll
+                for (int q = 0; q < PANEL_THREADS / 64; q++) { const uint32_t w = Q.wsum[q]; if (q < (tid >> 6)) woff += w; rtotal += (int)w; }
+                uint32_t rank = woff + incl - mysum;
+#pragma unroll
+                for (int q = 0; q < RANK_PPT; q++) {
+                    if (pbit[q]) rk[pwid[q]] = make_uint2(pbit[q], rank);
+                    rank += (uint32_t)__builtin_popcount(pbit[q]);
+                }
+            }                                           // (the barrier after the search stands between this and the products)
             panel_walk<NUM_PANEL_UNROLL, NUM_PANEL_PIPELINE>(A, B, pB0, deg, ibeg, pend, iend, first, pc, &Q,
                 [&](int32_t, int64_t pA, int64_t pB) -> PanelOperands<S> {
                     return fetch_operands(sr, A, B, apat, bpat, pA, pB);
                 },
                 [&](const int32_t (&i)[NUM_PANEL_UNROLL], const PanelOperands<S> (&r)[NUM_PANEL_UNROLL], const bool (&ok)[NUM_PANEL_UNROLL]) {
-                    bool todo[NUM_PANEL_UNROLL];
                     Z t[NUM_PANEL_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < NUM_PANEL_UNROLL; u++) t[u] = sr.mult(r[u].a, r[u].b, (int64_t)i[u], r[u].k, j);
+                    if (ranked) {
+#pragma unroll
+                        for (int u = 0; u < NUM_PANEL_UNROLL; u++) {
+                            const uint32_t wd = ((uint32_t)i[u] >> 5) - wbase32;       // the table is aligned to whole words
+                            const uint2 w = rk[ok[u] ? wd : 0u];
+                            const uint32_t bit = 1u << ((uint32_t)i[u] & 31u);
+                            if (ok[u] && (w.x & bit)) {
+                                const uint32_t slot = w.y + (uint32_t)__builtin_popcount(w.x & (bit - 1u));
+                                ridx[slot] = i[u];
+                                sr.atomic(&vals[slot], t[u]);
+                            }
+                        }
+                        return;
+                    }
+                    bool todo[NUM_PANEL_UNROLL];
 #pragma unroll
                     for (int u = 0; u < NUM_PANEL_UNROLL; u++) {
                         todo[u] = ok[u];
                         if constexpr (MASKED) todo[u] = todo[u] && mask_allows(M, i[u], j);
-                        t[u] = sr.mult(r[u].a, r[u].b, (int64_t)i[u], r[u].k, j);
                     }
                     if (direct) {
 #pragma unroll
                         for (int u = 0; u < NUM_PANEL_UNROLL; u++) if (todo[u]) {
-                            const uint32_t h = (uint32_t)(i[u] - base);
+                            const uint32_t h = (uint32_t)(i[u] - base32);
                             keys[h] = (int32_t)i[u];
                             sr.atomic(&vals[h], t[u]);
                         }
@@ -1709,43 +1909,52 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                         if (slot >= 0) sr.atomic(&vals[slot], t[u]); else Q.overflow = 1;
                     }
                 });
-            if (Q.overflow) {                            // uniform: raised before the barrier that ended the walk
+            if (!ranked && Q.overflow) {                 // uniform: raised before the barrier that ended the walk
                 width = (width > 1) ? (width >> 1) : 1;
                 shrink++;
                 st_overflows++;
-                for (int s = threadIdx.x; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
+                for (int s = tid; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
                 __syncthreads();
                 continue;
             }
-            // emit the panel (wave-aggregated positions, coalesced stores) and leave the table clean
             GBA_TICK(tkp1);
-            for (int s = threadIdx.x; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) {
-                const int32_t key = keys[s];
-                const bool occ = (key != HASH_EMPTY);
-                const unsigned long long m = __ballot(occ);
-                int wbase = 0;
-                if (lane64 == 0 && m) wbase = atomicAdd(&out_cursor, __builtin_popcountll(m));
-                wbase = __shfl(wbase, 0, 64);
-                if (occ) {
-                    const int64_t q = pC + wbase + __builtin_popcountll(m & ((1ull << lane64) - 1));
-                    Ci[q] = key;
-                    Cx[q] = (Z)vals[s];
-                    keys[s] = HASH_EMPTY;
-                    vals[s] = ident;
+            if (ranked) {
+                // in index order: Cx and Ci are straight copies; leave the table clean
+                Z *__restrict__ cx = Cx + pC;
+                int64_t *__restrict__ ci = Ci + pC;
+                for (int s = tid; s < rtotal; s += PANEL_THREADS) { cx[s] = (Z)vals[s]; ci[s] = (int64_t)ridx[s]; vals[s] = ident; }
+                const int nw = (int)(((lim - 1) >> 5) - (base >> 5)) + 1;
+                for (int s = tid; s < nw; s += PANEL_THREADS) rk[s] = make_uint2(0u, 0u);
+            } else {
+                // emit the panel (wave-aggregated positions, coalesced stores) and leave the table clean
+                for (int s = tid; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) {
+                    const int32_t key = keys[s];
+                    const bool occ = (key != HASH_EMPTY);
+                    const unsigned long long m = __ballot(occ);
+                    int wbase = 0;
+                    if (lane64 == 0 && m) wbase = atomicAdd(&out_cursor, __builtin_popcountll(m));
+                    wbase = __shfl(wbase, 0, 64);
+                    if (occ) {
+                        const int64_t q = pC + wbase + __builtin_popcountll(m & ((1ull << lane64) - 1));
+                        Ci[q] = key;
+                        Cx[q] = (Z)vals[s];
+                        keys[s] = HASH_EMPTY;
+                        vals[s] = ident;
+                    }
                 }
             }
             __syncthreads();
             GBA_TICK(tkp2);
             GBA_TOCK(&Q, 5, tkp1, tkp2); GBA_TOCK(&Q, 6, tkp0, tkp2);
-            const int d = out_cursor;
+            const int d = ranked ? rtotal : out_cursor;
             const int more = Q.more;
-            pC += d;
+            pC = uniform_i64(pC + d);
             pc.swap();
             first = false;
             base = lim;
             shrink = 0;
             st_panels++;
-            if (direct) { st_direct++; st_dent += (unsigned long long)d; } else st_hent += (unsigned long long)d;
+            if (direct || ranked) { st_direct++; st_dent += (unsigned long long)d; } else st_hent += (unsigned long long)d;
             if (d == 0) width = (width < cvlen) ? (width << 2) : width;
             else {
                 const int64_t covered = direct ? (int64_t)NUM_PANEL_SLOTS : width;
@@ -1758,12 +1967,12 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
             if (!more) break;
         }
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         atomicAdd(&next[1], st_panels); atomicAdd(&next[2], st_overflows);
         atomicAdd(&next[11], st_direct); atomicAdd(&next[12], st_dent); atomicAdd(&next[13], st_hent);
     }
 #ifdef GBA_PANEL_TICKS
-    if (threadIdx.x == 0) { Q.tk[7] = wall_clock64() - tkk; for (int q = 0; q < 8; q++) atomicAdd(&next[3 + q], Q.tk[q]); }
+    if (tid == 0) { Q.tk[7] = wall_clock64() - tkk; for (int q = 0; q < 8; q++) atomicAdd(&next[3 + q], Q.tk[q]); }
 #endif
 }
 
@@ -1828,6 +2037,9 @@ struct Saxpy3Plan {
     void *team_Hx = nullptr; uint64_t *team_Hf = nullptr;
     const int64_t *bstart = nullptr;        // panel boundaries of vector j: bounds[bstart[j] .. bstart[j+1])
     int64_t *bounds = nullptr;
+    const int64_t *pstart = nullptr;        // pattern of vector j, written by the symbolic sweep: the non-empty words of its
+    uint2 *pwords = nullptr;                //   bitmap, (word number, bits), in pwords[pstart[j] ..), in index order
+    int64_t *wbounds = nullptr;             //   and where the word of every boundary stands in that list (laid out like bounds)
     unsigned long long panel_stats[14] = {0};        // tasks pulled, panels swept, panels redone, stopwatch slots [3..10], direct panels, entries of direct / hashed panels
 };
 
@@ -1940,17 +2152,18 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         GBA_OK(next.alloc(128));
         GBA_HIP(hipMemsetAsync(next.p, 0, 128, st));
         auto k = (P.M.kind == 0) ? num_panel_kernel<S, false> : num_panel_kernel<S, true>;
-        const size_t lds = (size_t)NUM_PANEL_SLOTS * (sizeof(ACC) + 4);
+        const size_t lds = num_panel_lds<ACC>();
         GBA_OK(set_lds(k, lds));
         hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
                            sr, ntasks, tasks.as<PanelTask>(), P.A, P.B, P.M, P.cvlen, P.maxdeg,
-                           scratch.as<int64_t>(), next.as<unsigned long long>(), P.Cp, P.Ci, Cx, P.bstart, P.bounds);
+                           scratch.as<int64_t>(), next.as<unsigned long long>(), P.Cp, P.Ci, Cx, P.bstart, P.bounds,
+                           P.pstart, P.pwords, P.wbounds);
         GBA_HIP(hipGetLastError());
         mark(4);
         GBA_HIP(hipMemcpyAsync(P.panel_stats, next.p, 112, hipMemcpyDeviceToHost, st));
         GBA_HIP(hipStreamSynchronize(st));      // scratch is released on return
         if (getenv("GBA_PANEL_PROF"))
-            fprintf(stderr, "[gba] numeric panels %llu (direct %llu), entries from direct panels %llu, from hashed panels %llu\n",
+            fprintf(stderr, "[gba] numeric panels %llu (ranked or direct %llu), entries from those %llu, from hashed panels %llu\n",
                     P.panel_stats[1], P.panel_stats[11], P.panel_stats[12], P.panel_stats[13]);
     } else if (nb.count[BIN_GLOBAL] > 0) {
         const int64_t nf = (P.cvlen + 63) >> 6, ns = (nf + 63) >> 6;
@@ -2025,9 +2238,18 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
         GBA_OK(order_by_work_desc(sb.count[BIN_GLOBAL], sb.list(BIN_GLOBAL), P.vflops, &order));
         hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
                            sb.count[BIN_GLOBAL], order.as<int64_t>(), P.A, P.B, P.M, P.cvlen, P.maxdeg,
-                           scratch.as<int64_t>(), next.as<unsigned long long>(), cnt, P.bstart, P.bounds);
+                           scratch.as<int64_t>(), next.as<unsigned long long>(), cnt, P.bstart, P.bounds, P.pstart, P.pwords, P.wbounds);
         GBA_HIP(hipGetLastError());
         GBA_HIP(hipStreamSynchronize(st));
+#ifdef GBA_PANEL_TICKS
+        if (getenv("GBA_PANEL_PROF")) {
+            unsigned long long tk[8], zero[8] = {0};
+            GBA_HIP(hipMemcpyFromSymbol(tk, HIP_SYMBOL(g_sym_ticks), sizeof(tk)));
+            GBA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sym_ticks), zero, sizeof(zero)));
+            fprintf(stderr, "[gba] symbolic panel kernel, vectors %lld; 10 ns ticks summed over workgroups: search %llu (+wait %llu) prefix %llu "
+                    "products %llu (+wait %llu) kernel %llu\n", (long long)sb.count[BIN_GLOBAL], tk[0], tk[1], tk[2], tk[3], tk[4], tk[7]);
+        }
+#endif
     } else if (sb.count[BIN_GLOBAL] > 0) {
         const int64_t nf = (P.cvlen + 63) >> 6, ns = (nf + 63) >> 6;
         int64_t nblocks = 2 * (int64_t)ctx().num_cu;
@@ -2174,7 +2396,7 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         P.A.i32 = ai32.as<int32_t>();
         return GBA_SUCCESS;
     };
-    DevBuf bstart, bounds;
+    DevBuf bstart, bounds, pstart, patbuf, wbounds;
     if (P.sym.count[BIN_GLOBAL] > 0 && P.use_panels && P.maxdeg < PANEL_MAX_DEG) {
         GBA_OK(narrow_A());
         GBA_OK(bstart.alloc((size_t)(nvec + 1) * 8));
@@ -2188,6 +2410,30 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         GBA_OK(bounds.alloc((size_t)(room > 0 ? room : 1) * 8));
         P.bstart = bstart.as<int64_t>();
         P.bounds = bounds.as<int64_t>();
+        // Room for the patterns (one 8-byte pair per non-empty bitmap word: at most one per multiply-add and per 32
+        // indices): with them the numeric sweep ranks instead of hashing.  Without the room (or with
+        // GBA_PANEL_RANKED=0) it hashes as before.
+        const char *renv = getenv("GBA_PANEL_RANKED");               // read per call: tests switch it
+        const bool ranked = !(renv && atoi(renv) == 0);
+        if (ranked) {
+            GBA_OK(pstart.alloc((size_t)(nvec + 1) * 8));
+            hipLaunchKernelGGL(pattern_room_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, vflops.as<int64_t>(),
+                               (P.cvlen + 31) / 32, sym_blk2_max, pstart.as<int64_t>());
+            GBA_HIP(hipGetLastError());
+            GBA_OK(dev_cumsum_i64(pstart.as<int64_t>(), nvec, st));
+            int64_t proom = 0;
+            GBA_OK(dev_read_i64(pstart.as<int64_t>() + nvec, &proom));
+            size_t free_b = 0, total_b = 0, idle_b = 0;
+            GBA_HIP(hipMemGetInfo(&free_b, &total_b));
+            gba_pool_stats(&idle_b, nullptr);
+            if ((size_t)proom * 8 < (free_b + idle_b) / 3) {
+                GBA_OK(patbuf.alloc((size_t)(proom > 0 ? proom : 1) * 8));
+                GBA_OK(wbounds.alloc((size_t)(room > 0 ? room : 1) * 8));
+                P.pstart = pstart.as<int64_t>();
+                P.pwords = patbuf.as<uint2>();
+                P.wbounds = wbounds.as<int64_t>();
+            }
+        }
     }
     const int e1 = clock.mark();
 

@@ -69,6 +69,52 @@ def test_hashed_and_direct_panels(gba):
     assert_same(got, want, exact=True)
 
 
+def _sorted_within_vectors(M):
+    cnt = np.diff(M.p)
+    inner = np.ones(len(M.i), bool); inner[M.p[:-1][cnt > 0]] = False
+    return bool(np.all(np.diff(M.i)[inner[1:]] > 0))
+
+
+@pytest.mark.parametrize("ranked", ["1", "0"])
+def test_ranked_and_hashed_numeric_sweeps(gba, monkeypatch, ranked):
+    """The numeric sweep ranks products in the pattern the symbolic sweep wrote (default) or, without that pattern
+    (GBA_PANEL_RANKED=0, or no room for it), hashes them: same C either way; the ranked sweep leaves the heavy
+    vectors in index order."""
+    monkeypatch.setenv("GBA_PANEL_RANKED", ranked)
+    As, Bs = _heavy_pair(60000, 6, 5000, 12, 20000, 3, seed=21)
+    A, B = _mat(As), _mat(Bs)
+    got, rep = _run(gba, A, B, "PLUS_TIMES_FP64")
+    want = oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64")
+    assert rep.bin_vectors[3] == 6 and rep.panels > 6
+    assert_same(got, want, exact=True)
+    if ranked == "1":
+        assert _sorted_within_vectors(got)
+    # masked: entries the mask rules out are absent from the pattern, their products find no bit
+    rng = np.random.default_rng(22)
+    Ms = sp.random(60000, 6, density=0.4, random_state=rng, format="csc"); Ms.data[:] = 1
+    M = _mat(Ms, Type.BOOL)
+    for comp in (False, True):
+        got, rep = _run(gba, A, B, "MIN_PLUS_FP64", M, comp, True)
+        assert_same(got, oracle.saxpy3(M, comp, True, A, B, "MIN_PLUS_FP64"), exact=True, what=f"comp={comp}")
+
+
+def test_sparse_stretches_are_hashed_dense_ones_ranked(gba):
+    """Very sparse heavy vectors next to dense ones: a stretch of 6144 entries that spans more indices than the rank
+    table covers is hashed, narrower ones are ranked; both kinds alternate inside one vector."""
+    n = 4_000_000
+    As, Bs = _heavy_pair(n, 24, 12000, 2, 6000, 1, seed=23)        # (enough entries in B for the panel path)
+    Bs = Bs.tolil(); Bs[n - 1, 0] = 1; Bs = Bs.tocsc()                 # one neighbour at the far end
+    dense = sp.coo_matrix((np.ones(40000), (np.arange(1_000_000, 1_040_000), np.zeros(40000, int))), shape=(n, n)).tocsc()
+    As = (As + dense).tocsc()                                          # A(:,0): a dense run of 40000 indices
+    Bs = Bs.tolil(); Bs[0, :] = 1; Bs = Bs.tocsc()                     # every vector names it
+    A, B = _mat(As), _mat(Bs)
+    got, rep = _run(gba, A, B, "PLUS_TIMES_FP64")
+    want = oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64")
+    cnt = np.diff(want.p)
+    assert rep.bin_vectors[3] == 24 and cnt.min() > 4096 + 40000
+    assert_same(got, want, exact=True)
+
+
 def test_fully_dense_vectors_use_direct_panels(gba):
     As, Bs = _heavy_pair(20000, 3, 300, 4, 5000, 2, seed=2, dense_cols=2)
     dense_k = np.flatnonzero(np.diff(As.indptr) == 20000)
