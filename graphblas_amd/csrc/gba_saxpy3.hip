@@ -210,6 +210,11 @@ static constexpr int NUM_WAVE_SLOTS = 512,   NUM_WAVE_MAX = 256;
 static constexpr int NUM_BLK1_SLOTS = 4096,  NUM_BLK1_MAX = 2048,  NUM_BLK1_THREADS = 256;
 static constexpr int NUM_BLK2_SLOTS = 8192,  NUM_BLK2_MAX = 4096,  NUM_BLK2_THREADS = 512;
 static constexpr int GLOBAL_THREADS = 512;
+// one-pass road for a few light vectors (frontier steps): at most SMALL_NVEC vectors of at most SMALL_ROOM
+// multiply-adds each, accumulated in the second block bin's table (three quarters full at worst)
+static constexpr int SMALL_NVEC = 256, SMALL_ROOM = 6144;
+static constexpr int64_t SMALL_BNZ = 16384;
+static_assert(SMALL_ROOM * 4 <= NUM_BLK2_SLOTS * 3, "the one-pass table never fills up");
 
 struct BinLimits { int64_t wave_max, blk1_max, blk2_max; };
 
@@ -653,7 +658,8 @@ num_wave_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A,
 template <class S, int SLOTS, int THREADS>
 __global__ void __launch_bounds__(THREADS)
 num_block_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int lpa,
-                 const int64_t *__restrict__ Cp, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx) {
+                 const int64_t *__restrict__ Cp, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx,
+                 const int64_t *__restrict__ small_flops, int64_t *__restrict__ small_cnt) {
     using Z = typename S::z_t; using ACC = typename S::acc_t;
     extern __shared__ __align__(16) unsigned char smem[];
     ACC *vals = reinterpret_cast<ACC *>(smem);
@@ -661,7 +667,14 @@ num_block_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
     __shared__ int cursor;
     __shared__ int longq[LONGQ_CAP];
     __shared__ int longn;
-    const int64_t j = list[blockIdx.x];
+    // One-pass mode for a product of a few light vectors (small_cnt given): no list, no symbolic count.  Vector
+    // blockIdx.x is emitted into a slab of SMALL_ROOM entries of its own and its entry count is reported, or -1
+    // when its multiply-adds could overfill the table (the caller then takes the two-pass road).
+    const int64_t j = small_cnt ? (int64_t)blockIdx.x : list[blockIdx.x];
+    if (small_cnt && small_flops[j] > (int64_t)SMALL_ROOM) {
+        if (threadIdx.x == 0) small_cnt[j] = -1;
+        return;
+    }
     const ACC ident = (ACC)sr.identity();
     for (int s = threadIdx.x; s < SLOTS; s += THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
     if (threadIdx.x == 0) cursor = 0;
@@ -675,7 +688,7 @@ num_block_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
         sr.atomic(&vals[h], t);
     });
     __syncthreads();
-    const int64_t pC = Cp[j];
+    const int64_t pC = small_cnt ? j * (int64_t)SMALL_ROOM : Cp[j];
     for (int s = threadIdx.x; s < SLOTS; s += THREADS) {
         const int32_t key = keys[s];
         if (key != HASH_EMPTY) {
@@ -683,6 +696,22 @@ num_block_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
             Ci[pC + pos] = key;
             Cx[pC + pos] = (Z)vals[s];
         }
+    }
+    if (small_cnt) {
+        __syncthreads();
+        if (threadIdx.x == 0) small_cnt[j] = cursor;
+    }
+}
+
+// one-pass mode, second step: the slabs are packed into C (Cp holds the prefix sum of the counts)
+template <class Z>
+__global__ void __launch_bounds__(256)
+small_pack_kernel(const int64_t *__restrict__ Cp, const int64_t *__restrict__ slab_i, const Z *__restrict__ slab_x,
+                  int64_t *__restrict__ Ci, Z *__restrict__ Cx) {
+    const int64_t j = blockIdx.x, pC = Cp[j], n = Cp[j + 1] - pC;
+    for (int64_t e = threadIdx.x; e < n; e += 256) {
+        Ci[pC + e] = slab_i[j * (int64_t)SMALL_ROOM + e];
+        Cx[pC + e] = slab_x[j * (int64_t)SMALL_ROOM + e];
     }
 }
 
@@ -2115,7 +2144,8 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         const size_t lds = (size_t)NUM_BLK1_SLOTS * (sizeof(ACC) + 4);
         GBA_OK(set_lds(k, lds));
         hipLaunchKernelGGL(k, dim3((unsigned)nb.count[BIN_BLK1]), dim3(NUM_BLK1_THREADS), lds, st,
-                           sr, nb.count[BIN_BLK1], nb.list(BIN_BLK1), P.A, P.B, P.M, P.lpa, P.Cp, P.Ci, Cx);
+                           sr, nb.count[BIN_BLK1], nb.list(BIN_BLK1), P.A, P.B, P.M, P.lpa, P.Cp, P.Ci, Cx,
+                           (const int64_t *)nullptr, (int64_t *)nullptr);
     }
     mark(2);
     if (nb.count[BIN_BLK2] > 0) {
@@ -2123,7 +2153,8 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         const size_t lds = (size_t)NUM_BLK2_SLOTS * (sizeof(ACC) + 4);
         GBA_OK(set_lds(k, lds));
         hipLaunchKernelGGL(k, dim3((unsigned)nb.count[BIN_BLK2]), dim3(NUM_BLK2_THREADS), lds, st,
-                           sr, nb.count[BIN_BLK2], nb.list(BIN_BLK2), P.A, P.B, P.M, P.lpa, P.Cp, P.Ci, Cx);
+                           sr, nb.count[BIN_BLK2], nb.list(BIN_BLK2), P.A, P.B, P.M, P.lpa, P.Cp, P.Ci, Cx,
+                           (const int64_t *)nullptr, (int64_t *)nullptr);
     }
     GBA_HIP(hipGetLastError());
     mark(3);
@@ -2315,6 +2346,72 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         if ((double)hw[0] < 0.01 * (double)hw[1]) {
             if (mask_applied) *mask_applied = false;
             return GBA_NO_VALUE;
+        }
+    }
+    // A few light vectors (the late levels of a traversal): one pass.  Every vector is accumulated in an LDS table
+    // and emitted into a slab of its own, the counts come back in one read, the slabs are packed into C -- two
+    // round trips to the host instead of the binning, counting and sizing of the two-pass road.
+    if (nvec > 0 && nvec <= SMALL_NVEC && B->nvals <= SMALL_BNZ && !getenv("GBA_NO_ONE_PASS")) {
+        const size_t zsize = type_size(c.ztype);
+        DevBuf scnt, slab_i, slab_x;
+        GBA_OK(scnt.alloc((size_t)nvec * 8));
+        GBA_OK(slab_i.alloc((size_t)nvec * SMALL_ROOM * 8));
+        GBA_OK(slab_x.alloc((size_t)nvec * SMALL_ROOM * zsize));
+        GBA_OK(with_semiring(c, [&](auto sr) -> gba_info {
+            using S = decltype(sr); using Z = typename S::z_t; using ACC = typename S::acc_t;
+            auto k = num_block_kernel<S, NUM_BLK2_SLOTS, NUM_BLK2_THREADS>;
+            const size_t lds = (size_t)NUM_BLK2_SLOTS * (sizeof(ACC) + 4);
+            GBA_OK(set_lds(k, lds));
+            hipLaunchKernelGGL(k, dim3((unsigned)nvec), dim3(NUM_BLK2_THREADS), lds, st, sr, nvec, (const int64_t *)nullptr,
+                               P.A, P.B, P.M, P.lpa, (const int64_t *)nullptr, slab_i.as<int64_t>(), slab_x.as<Z>(),
+                               vflops.as<int64_t>(), scnt.as<int64_t>());
+            GBA_HIP(hipGetLastError());
+            return GBA_SUCCESS;
+        }));
+        std::vector<int64_t> hp((size_t)nvec + 1, 0);
+        GBA_HIP(hipMemcpyAsync(hp.data() + 1, scnt.p, (size_t)nvec * 8, hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipStreamSynchronize(st));
+        bool fits = true;
+        for (int64_t j = 1; j <= nvec; j++) { if (hp[(size_t)j] < 0) { fits = false; break; } hp[(size_t)j] += hp[(size_t)j - 1]; }
+        if (fits) {
+            const int64_t cnz = hp[(size_t)nvec];
+            DevBuf Cp, Ci, Cx;
+            GBA_OK(Cp.alloc((size_t)(nvec + 1) * 8));
+            GBA_OK(Ci.alloc((size_t)(cnz > 0 ? cnz : 1) * 8));
+            GBA_OK(Cx.alloc((size_t)(cnz > 0 ? cnz : 1) * zsize));
+            GBA_HIP(hipMemcpyAsync(Cp.p, hp.data(), (size_t)(nvec + 1) * 8, hipMemcpyHostToDevice, st));
+            if (cnz > 0) {
+                GBA_OK(with_semiring(c, [&](auto sr) -> gba_info {
+                    using Z = typename decltype(sr)::z_t;
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(small_pack_kernel<Z>), dim3((unsigned)nvec), dim3(256), 0, st,
+                                       Cp.as<int64_t>(), slab_i.as<int64_t>(), slab_x.as<Z>(), Ci.as<int64_t>(), Cx.as<Z>());
+                    GBA_HIP(hipGetLastError());
+                    return GBA_SUCCESS;
+                }));
+            }
+            GBA_HIP(hipStreamSynchronize(st));          // hp and the slabs are released on return
+            if (rep) {
+                const int e9 = clock.mark();
+                rep->phase_ms[0] = clock.ms(e0, e9);
+                rep->kernel_ms = clock.ms(e0, e9);
+                rep->cnz = cnz;
+            }
+            C->vlen = A->vlen; C->vdim = B->vdim; C->nvec = nvec; C->nvals = cnz;
+            C->p = reinterpret_cast<int64_t *>(Cp.release());
+            C->h = nullptr;
+            C->i = reinterpret_cast<int64_t *>(Ci.release());
+            C->x = Cx.release();
+            C->b = nullptr;
+            C->nzombies = 0;
+            C->type = c.ztype;
+            C->sparsity = GBA_SPARSE;
+            C->mem = GBA_MEM_DEVICE;
+            C->iso = false;
+            C->is_csc = B->is_csc;
+            C->jumbled = true;
+            if (mask_applied) *mask_applied = (M != nullptr);
+            if (do_sort) GBA_OK(matrix_wait(C));
+            return GBA_SUCCESS;
         }
     }
     // a few very heavy vectors: the whole grid works on each of them (team kernels)

@@ -209,3 +209,49 @@ def test_partition_by_flops_matches_the_host_split(gba):
         loads = np.diff(prefix[np.array(part)])
         assert loads.max() <= prefix[-1] / nparts + rf.max()
     dA.free()
+
+
+@pytest.mark.parametrize("sr,t", [("PLUS_TIMES_FP64", Type.FP64), ("ANY_SECONDI_INT64", Type.INT64), ("MIN_PLUS_FP32", Type.FP32),
+                                  ("LOR_LAND_BOOL", Type.BOOL), ("PLUS_TIMES_INT8", Type.INT8)])
+def test_one_pass_road_for_a_few_light_vectors(gba, monkeypatch, sr, t):
+    """At most 256 vectors in B with few entries (the late levels of a traversal): accumulated and emitted in one pass,
+    counts read back once.  Same C as the two-pass road (GBA_NO_ONE_PASS=1), masked or not, empty vectors included."""
+    n = 20000
+    rng = np.random.default_rng(31)
+    A = _csc(_rand(n, n, 4e-4, seed=32), t)                    # about 8 entries per vector
+    nb = 9
+    cols = np.repeat(np.arange(nb), [0, 1, 3, 40, 200, 0, 700, 5, 64])
+    rows = np.concatenate([rng.choice(n, k, replace=False) for k in (0, 1, 3, 40, 200, 0, 700, 5, 64)]).astype(np.int64)
+    Bs = sp.coo_matrix((rng.integers(1, 5, len(rows)).astype(np.float64), (rows, cols)), shape=(n, nb)).tocsc()
+    B = _csc(Bs, t)
+    M = Matrix.dense(np.ones((n, nb), np.int8), present=rng.random((n, nb)) < 0.5, by_row=False)
+    for mask, comp in ((None, False), (M, False), (M, True)):
+        want = oracle.saxpy3(mask, comp, True, A, B, sr)
+        for off in ("", "1"):
+            if off:
+                monkeypatch.setenv("GBA_NO_ONE_PASS", "1")
+            else:
+                monkeypatch.delenv("GBA_NO_ONE_PASS", raising=False)
+            got, rep, _ = _run(gba, A, B, sr, mask, comp, True)
+            what = f"{sr} mask={mask is not None} comp={comp} one_pass={not off}"
+            if sr.startswith("ANY"):
+                assert_same(got, want, check_values=False, what=what)
+            else:
+                assert_same(got, want, exact=True, what=what)
+
+
+def test_one_pass_road_hands_over_when_a_vector_is_too_heavy(gba):
+    """One vector of the few has more multiply-adds than the one-pass table takes: the call falls back to the
+    two-pass road and the result is the same."""
+    n = 30000
+    rng = np.random.default_rng(33)
+    S = _rand(n, n, 3e-4, seed=34).tolil()
+    S[rng.choice(n, 9000, replace=False), 7] = 2                # A(:,7) is long
+    A = _csc(S.tocsc())
+    rows = np.concatenate([[7, 11, 12], rng.choice(n, 30, replace=False)]).astype(np.int64)
+    cols = np.concatenate([[0, 0, 0], np.ones(30, np.int64)])
+    B = _csc(sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, 2)).tocsc())
+    got, rep, _ = _run(gba, A, B, "PLUS_TIMES_FP64")
+    want = oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64")
+    assert np.diff(want.p)[0] > 6144
+    assert_same(got, want, exact=True)
