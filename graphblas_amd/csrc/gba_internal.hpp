@@ -28,6 +28,7 @@ struct Context {
     int device = -1;
     hipStream_t stream = nullptr;
     int num_cu = 256;
+    size_t total_mem = 0;           // bytes of device memory (read once in gba_init)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;        // KernelTimer (inside the library)
     hipEvent_t tm0 = nullptr, tm1 = nullptr;        // gba_timer_start / gba_timer_stop (the caller's stopwatch)
 };

@@ -512,7 +512,7 @@ gba_info gba_init(int device) {
     c.device = device;
     c.inited = true;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) pool().set_limit(total_b / 2 + total_b / 8);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { c.total_mem = total_b; pool().set_limit(total_b / 2 + total_b / 8); }
     if (const char *e = getenv("GBA_POOL_LIMIT_MB")) pool().set_limit((size_t)strtoull(e, nullptr, 10) << 20);
     return GBA_SUCCESS;
 }

@@ -2418,40 +2418,46 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     DevBuf team_list, team_Hx, team_Hf, symwork;
     const int64_t *symflops = vflops.as<int64_t>();
     {
-        DevBuf tc; GBA_OK(tc.alloc(8));
-        GBA_HIP(hipMemsetAsync(tc.p, 0, 8, st));
-        GBA_OK(team_list.alloc(TEAM_MAX_VECTORS * 8));
+        // the count and the list come back in one read
+        GBA_OK(team_list.alloc((1 + TEAM_MAX_VECTORS) * 8));
+        unsigned long long *tcount = team_list.as<unsigned long long>();
+        int64_t *tlist = team_list.as<int64_t>() + 1;
+        GBA_HIP(hipMemsetAsync(tcount, 0, 8, st));
         if (nvec > 0) {
             int64_t blocks = ceil_div(nvec, 256); if (blocks > 2048) blocks = 2048;
             // With only a few vectors in all (a frontier step has one) nothing else can fill the chip: every vector
             // too heavy for a workgroup's LDS table is then worked on by the whole grid.
             const int64_t min_flops = (nvec <= TEAM_MAX_VECTORS) ? (int64_t)SYM_BLK1_MAX : TEAM_MIN_FLOPS;
             hipLaunchKernelGGL(team_select_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, vflops.as<int64_t>(),
-                               min_flops, tc.as<unsigned long long>(), team_list.as<int64_t>(), TEAM_MAX_VECTORS);
+                               min_flops, tcount, tlist, TEAM_MAX_VECTORS);
         }
-        int64_t nteam = 0;
-        GBA_OK(dev_read_i64(tc.as<int64_t>(), &nteam));
+        int64_t hteam[1 + TEAM_MAX_VECTORS];
+        GBA_HIP(hipMemcpyAsync(hteam, team_list.p, sizeof(hteam), hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipStreamSynchronize(st));
+        const int64_t nteam = hteam[0];
         const size_t acc_size = type_size(c.ztype) < 4 ? 4 : type_size(c.ztype);
         const int64_t nf = (P.cvlen + 63) >> 6;
-        size_t free_b = 0, total_b = 0, idle_b = 0;
-        if (nteam > 0) {                                     // (a driver query: not on the path of calls without a team)
+        const size_t need = (size_t)nteam * ((size_t)P.cvlen * acc_size + (size_t)nf * 8);
+        // the workspaces must leave room for the product; a need of a few per cent of the device is not worth the
+        // driver query that tells how much is free
+        bool room = need < ctx().total_mem / 32;
+        if (nteam > 0 && !room) {
+            size_t free_b = 0, total_b = 0, idle_b = 0;
             GBA_HIP(hipMemGetInfo(&free_b, &total_b));
             gba_pool_stats(&idle_b, nullptr);
+            room = need < (free_b + idle_b) / 4;
         }
-        const size_t need = (size_t)nteam * ((size_t)P.cvlen * acc_size + (size_t)nf * 8);
         int64_t team_max = TEAM_MAX_VECTORS;                 // GBA_TEAM_MAX_VECTORS=0 turns the team path off (tests)
         if (const char *e = getenv("GBA_TEAM_MAX_VECTORS")) { team_max = atoll(e); if (team_max > TEAM_MAX_VECTORS) team_max = TEAM_MAX_VECTORS; }
-        if (nteam > 0 && nteam <= team_max && need < (free_b + idle_b) / 4) {
-            P.team.resize((size_t)nteam);
-            GBA_HIP(hipMemcpyAsync(P.team.data(), team_list.p, (size_t)nteam * 8, hipMemcpyDeviceToHost, st));
-            GBA_HIP(hipStreamSynchronize(st));
+        if (nteam > 0 && nteam <= team_max && room) {
+            P.team.assign(hteam + 1, hteam + 1 + nteam);
             GBA_OK(team_Hx.alloc((size_t)nteam * (size_t)P.cvlen * acc_size));
             GBA_OK(team_Hf.alloc((size_t)nteam * (size_t)nf * 8));
             P.team_Hx = team_Hx.p; P.team_Hf = team_Hf.as<uint64_t>();
             // the bins must not see them
             GBA_OK(symwork.alloc((size_t)(nvec + 1) * 8));
             GBA_HIP(hipMemcpyAsync(symwork.p, vflops.p, (size_t)(nvec + 1) * 8, hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(zero_listed_kernel, dim3(1), dim3(256), 0, st, (int)nteam, team_list.as<int64_t>(), symwork.as<int64_t>());
+            hipLaunchKernelGGL(zero_listed_kernel, dim3(1), dim3(256), 0, st, (int)nteam, team_list.as<int64_t>() + 1, symwork.as<int64_t>());
             GBA_HIP(hipGetLastError());
             symflops = symwork.as<int64_t>();
         }
@@ -2461,7 +2467,9 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     // The panel kernels need sorted A and read its indices from a 32-bit copy made per call: a pass over all of
     // A, which a small product (a short frontier against a large graph) must not pay for.  Such products
     // keep the memory-side accumulator kernels.
-    P.use_panels = !A->jumbled;
+    // when the team takes every vector (the one vector of a frontier step) there is nothing to bin, count or size
+    const bool all_team = nvec > 0 && (int64_t)P.team.size() == nvec;
+    P.use_panels = !A->jumbled && !all_team;
     if (P.use_panels && B->nvals < A->nvals / 32 && nvec > 0) {
         // few entries in B: the product may still be large (a block of hub rows); the multiply-adds decide
         DevBuf w; GBA_OK(w.alloc(16));
@@ -2475,9 +2483,10 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         P.use_panels = (double)hw[0] >= (double)A->nvals / 8;
     }
     const int64_t sym_blk2_max = P.use_panels ? SYM_BLK1_MAX : SYM_BLK2_MAX;
-    GBA_OK(build_bins(nvec, symflops, false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, sym_blk2_max}, &P.sym));
+    if (!all_team) GBA_OK(build_bins(nvec, symflops, false, BinLimits{SYM_WAVE_MAX, SYM_BLK1_MAX, sym_blk2_max}, &P.sym));
     P.vflops = vflops.as<int64_t>();
-    if (P.sym.count[BIN_GLOBAL] > 0 || !P.team.empty()) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
+    if (all_team && nvec == 1) P.maxdeg = B->nvals;         // (the one vector holds every entry of B)
+    else if (P.sym.count[BIN_GLOBAL] > 0 || !P.team.empty()) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
     // the panel kernels read the indices of A from a 32-bit copy (vlen < 2^31 was checked above)
     DevBuf ai32;
     auto narrow_A = [&]() -> gba_info {
@@ -2542,13 +2551,13 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     const int e2 = clock.mark();
 
     // numeric bins use the exact counts, taken before the prefix sum
-    {
+    if (!all_team) {
         const int64_t *numwork = Cp.as<int64_t>();
         DevBuf nw;
         if (!P.team.empty()) {
             GBA_OK(nw.alloc((size_t)(nvec + 1) * 8));
             GBA_HIP(hipMemcpyAsync(nw.p, Cp.p, (size_t)(nvec + 1) * 8, hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(zero_listed_kernel, dim3(1), dim3(256), 0, st, (int)P.team.size(), team_list.as<int64_t>(), nw.as<int64_t>());
+            hipLaunchKernelGGL(zero_listed_kernel, dim3(1), dim3(256), 0, st, (int)P.team.size(), team_list.as<int64_t>() + 1, nw.as<int64_t>());
             GBA_HIP(hipGetLastError());
             numwork = nw.as<int64_t>();
         }
