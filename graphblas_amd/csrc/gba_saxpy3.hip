@@ -988,9 +988,10 @@ team_gather_kernel(int64_t nf, const uint64_t *__restrict__ Hf, const typename S
 // neighbour with nothing inside the panel is dismissed from those coalesced
 // arrays alone, without touching A.
 static constexpr int PANEL_THREADS = 1024;
-static constexpr int PANEL_NPT = 2;                                   // neighbours searched per thread per step
+static constexpr int PANEL_NPT = 1;                                   // neighbours searched per thread per step
 static constexpr int PANEL_STEP = PANEL_THREADS * PANEL_NPT;
-static constexpr int PANEL_SEGCAP = 4 * PANEL_THREADS;                // runs queued in LDS before they are expanded
+static constexpr int PANEL_SEGCAP = PANEL_THREADS;                    // runs queued in LDS before they are expanded: one search step's worth (LDS spent on
+                                                                      // the queue is LDS taken from the tables, and larger tables mean fewer panels)
 static constexpr int PANEL_UNROLL_MAX = 8;
 // two windows per wave in flight (the loads of one issued before the other is consumed)?
 static constexpr bool SYM_PANEL_PIPELINE = false, NUM_PANEL_PIPELINE = false;
@@ -998,13 +999,12 @@ static constexpr int SYM_PANEL_UNROLL = 4, NUM_PANEL_UNROLL = 2;            // p
 static constexpr int PANEL_T_BITS = 24;
 static constexpr int64_t PANEL_MAX_DEG = (int64_t)1 << PANEL_T_BITS;
 static constexpr int64_t PANEL_MAX_WIDTH = (int64_t)1 << 20;          // (SEGCAP-1) runs of this length stay below 2^32
-static constexpr int SYM_PANEL_WORDS = 24576;                         // 96 KiB of LDS
+static constexpr int SYM_PANEL_WORDS = 32768;                         // 128 KiB of LDS
 static constexpr int64_t SYM_PANEL_WIDTH = (int64_t)SYM_PANEL_WORDS * 32;
-static constexpr int NUM_PANEL_SLOTS = 8192;
+static constexpr int NUM_PANEL_SLOTS = 11264;                        // (any multiple of PANEL_THREADS: slots are picked by multiply-shift)
 static constexpr int NUM_PANEL_TARGET = 3000;                         // distinct indices aimed at per panel (no boundaries known)
-static constexpr int NUM_PANEL_FIT = 6144;                            // entries between two recorded boundaries
+static constexpr int NUM_PANEL_FIT = 8448;                            // entries between two recorded boundaries: three quarters of the slots
 static constexpr int SYM_WORDS_PER_THREAD = SYM_PANEL_WORDS / PANEL_THREADS;
-static constexpr int SYM_STAGE = PANEL_SEGCAP;                        // (word, bits) pairs that fit the run queue's position array
 static constexpr int PANEL_PROBE_LIMIT = 48;
 static constexpr int64_t PANEL_INF = (int64_t)1 << 62;
 static constexpr int PANEL_SCRATCH_ARRAYS = 5;
@@ -1075,13 +1075,14 @@ __device__ inline int64_t first_ge(const int32_t *__restrict__ X, int64_t lo, in
 // append and the call; ends on a barrier with the queue empty.
 template <int PANEL_UNROLL, bool PANEL_PIPELINE, class Load, class Apply>
 __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSegs *S, Load load, Apply apply) {
-    static_assert(PANEL_SEGCAP == 4 * PANEL_THREADS && PANEL_SEGCAP <= 64 * 64, "four queue entries per thread in the scan; two 64-way steps find a run");
+    constexpr int QPT = PANEL_SEGCAP / PANEL_THREADS;      // queue entries per thread in the scan
+    static_assert(QPT * PANEL_THREADS == PANEL_SEGCAP && PANEL_SEGCAP <= 64 * 64, "two 64-way steps find a run");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     GBA_TICK(tke0);
-    const int b4 = tid * 4;
-    uint32_t v[4], s = 0;
+    const int b4 = tid * QPT;
+    uint32_t v[QPT], s = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) { v[q] = (b4 + q < n) ? S->off[b4 + q] : 0u; s += v[q]; }
+    for (int q = 0; q < QPT; q++) { v[q] = (b4 + q < n) ? S->off[b4 + q] : 0u; s += v[q]; }
     uint32_t incl = s;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
@@ -1092,7 +1093,7 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
     for (int q = 0; q < PANEL_THREADS / 64; q++) { const uint32_t w = S->wsum[q]; if (q < wv) woff += w; T += w; }
     uint32_t run = woff + incl - s;
 #pragma unroll
-    for (int q = 0; q < 4; q++) if (b4 + q < n) { S->off[b4 + q] = run; run += v[q]; }
+    for (int q = 0; q < QPT; q++) if (b4 + q < n) { S->off[b4 + q] = run; run += v[q]; }
     if (tid == 0) { S->nseg = 0; S->wnext = 0; }
     __syncthreads();
     GBA_TICK(tke1);
@@ -1477,7 +1478,7 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
         GBA_TOCK(S, 0, tk0, tk1); GBA_TOCK(S, 1, tk1, tk2);
         const int ns = S->nseg;
         const bool last = t0 + PANEL_STEP >= deg;
-        if (ns >= PANEL_SEGCAP - PANEL_STEP || (last && ns > 0)) {
+        if (ns > 0 && (ns > PANEL_SEGCAP - PANEL_STEP || last)) {
             panel_expand<PANEL_UNROLL, PANEL_PIPELINE>(A, pB0, ns, S, load, apply);
             if (S->overflow) return;
         } else {
@@ -1579,8 +1580,8 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                     }
                 });
             // count in index order: each thread owns SYM_WORDS_PER_THREAD consecutive words, read once with 16-byte
-            // LDS loads (conflict-free at this stride); the packed sum carries the entries (low 20 bits: a panel has
-            // at most 2^19.6) and the non-empty words (above) of the slice
+            // LDS loads (conflict-free at this stride); the packed sum carries the entries (low 21 bits: a panel has
+            // at most 2^20) and the non-empty words (above) of the slice
             const int w0 = tid * SYM_WORDS_PER_THREAD;
             uint4 *b4 = reinterpret_cast<uint4 *>(bm + w0);
             uint64_t both = 0;
@@ -1588,9 +1589,9 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
             for (int q = 0; q < SYM_WORDS_PER_THREAD / 4; q++) {
                 const uint4 v = b4[q];
                 both += (uint64_t)(__builtin_popcount(v.x) + __builtin_popcount(v.y) + __builtin_popcount(v.z) + __builtin_popcount(v.w))
-                      + ((uint64_t)((v.x != 0u) + (v.y != 0u) + (v.z != 0u) + (v.w != 0u)) << 20);
+                      + ((uint64_t)((v.x != 0u) + (v.y != 0u) + (v.z != 0u) + (v.w != 0u)) << 21);
             }
-            const int mine = (int)(both & 0xfffffu), nzc = (int)(both >> 20);
+            const int mine = (int)(both & 0x1fffffu), nzc = (int)(both >> 21);
             uint64_t incl2 = both;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint64_t u = __shfl_up((unsigned long long)incl2, d, 64); if (lane >= d) incl2 += u; }
@@ -1600,9 +1601,9 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
 #pragma unroll
             for (int q = 0; q < PANEL_THREADS / 64; q++) { const uint64_t w = Q.wsum2[q]; if (q < wv) woff2 += w; total2 += w; }
             const uint64_t excl2 = woff2 + incl2 - both;
-            const int total = (int)(total2 & 0xfffffu), nztotal = (int)(total2 >> 20);
-            const int nzlo = (int)(excl2 >> 20);                // non-empty words of the panel before this thread's slice
-            const int64_t lo = seen + (int64_t)(excl2 & 0xfffffu);   // entries before this thread's slice
+            const int total = (int)(total2 & 0x1fffffu), nztotal = (int)(total2 >> 21);
+            const int nzlo = (int)(excl2 >> 21);                // non-empty words of the panel before this thread's slice
+            const int64_t lo = seen + (int64_t)(excl2 & 0x1fffffu);   // entries before this thread's slice
             const int64_t m = lo / NUM_PANEL_FIT + 1;       // the next multiple to be crossed
             if (m * NUM_PANEL_FIT <= lo + mine) {
                 int r = (int)(m * NUM_PANEL_FIT - lo);      // the r-th set bit of the slice, 1-based
@@ -1718,10 +1719,13 @@ panel_task_fill_kernel(int64_t nlist, const int64_t *__restrict__ list, const in
     }
 }
 
-// Multiplicative (Fibonacci) hash into NUM_PANEL_SLOTS = 2^13 slots.  The order in which a panel's
+// Multiplicative (Fibonacci) hash, reduced to [0, NUM_PANEL_SLOTS) by a second multiply.  The order in which a panel's
 // entries leave the table is free (C is returned jumbled), so the function need not be GB_HASHF.
-__device__ inline uint32_t panel_hash(int32_t key) { return ((uint32_t)key * 0x9E3779B1u) >> 19; }
-static_assert(NUM_PANEL_SLOTS == (1 << 13), "panel_hash keeps the top 13 bits");
+__device__ inline uint32_t panel_hash(int32_t key) {
+    return (uint32_t)(((uint64_t)((uint32_t)key * 0x9E3779B1u) * (uint64_t)NUM_PANEL_SLOTS) >> 32);
+}
+static_assert(NUM_PANEL_SLOTS % PANEL_THREADS == 0 && NUM_PANEL_SLOTS % 4 == 0, "whole buckets; the emit loop is wave-uniform");
+static_assert(NUM_PANEL_FIT * 4 <= NUM_PANEL_SLOTS * 3, "a stretch fills the table to three quarters at most");
 
 // Ranked panels.  When the symbolic sweep wrote the pattern of C(:,j) down -- the non-empty words of its bitmap
 // as (word number, bits) pairs in index order, and where the word of every boundary stands in that list -- a
@@ -1733,8 +1737,8 @@ static_assert(NUM_PANEL_SLOTS == (1 << 13), "panel_hash keeps the top 13 bits");
 // (masked out) find their bit clear and are dropped, so the mask is not consulted.  The panel leaves vals in
 // index order: Cx and Ci are straight copies.  Wider (sparser) stretches are hashed as before; the two table
 // layouts share the same LDS and are re-initialised when the kind of panel changes.
-static constexpr int RANK_WORDS = 4608;                               // 36 KiB of LDS
-static constexpr int RANK_PPT = 5;                                    // pairs per thread: a ranked stretch has at most RANK_WORDS + 1
+static constexpr int RANK_WORDS = 5888;                               // 46 KiB of LDS
+static constexpr int RANK_PPT = 6;                                    // pairs per thread: a ranked stretch has at most RANK_WORDS + 1
 static_assert(RANK_PPT * PANEL_THREADS > RANK_WORDS, "all pairs of a ranked stretch are held at once");
 static_assert((int64_t)RANK_WORDS * 32 <= PANEL_MAX_WIDTH, "ranked panel too wide for 32-bit product offsets");
 
@@ -1927,7 +1931,7 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                             if (pos < 0) {
                                 const int e = (kk.x == HASH_EMPTY) ? 0 : (kk.y == HASH_EMPTY) ? 1 : (kk.z == HASH_EMPTY) ? 2
                                             : (kk.w == HASH_EMPTY) ? 3 : -1;
-                                if (e < 0) { hb = (hb + 4) & (NUM_PANEL_SLOTS - 1); continue; }     // bucket full: next one
+                                if (e < 0) { hb = (hb + 4 < (uint32_t)NUM_PANEL_SLOTS) ? hb + 4 : 0u; continue; }     // bucket full: next one
                                 const int32_t old = atomicCAS(&keys[hb + e], HASH_EMPTY, key);
                                 if (old != HASH_EMPTY && old != key) continue;                      // lost the slot: look again
                                 pos = e;
