@@ -655,7 +655,7 @@ num_wave_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A,
     }
 }
 
-template <class S, int SLOTS, int THREADS>
+template <class S, int SLOTS, int THREADS, bool ONE_PASS = false>
 __global__ void __launch_bounds__(THREADS)
 num_block_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int lpa,
                  const int64_t *__restrict__ Cp, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx,
@@ -667,13 +667,15 @@ num_block_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
     __shared__ int cursor;
     __shared__ int longq[LONGQ_CAP];
     __shared__ int longn;
-    // One-pass mode for a product of a few light vectors (small_cnt given): no list, no symbolic count.  Vector
+    // One-pass mode for a product of a few light vectors (ONE_PASS): no list, no symbolic count.  Vector
     // blockIdx.x is emitted into a slab of SMALL_ROOM entries of its own and its entry count is reported, or -1
     // when its multiply-adds could overfill the table (the caller then takes the two-pass road).
-    const int64_t j = small_cnt ? (int64_t)blockIdx.x : list[blockIdx.x];
-    if (small_cnt && small_flops[j] > (int64_t)SMALL_ROOM) {
-        if (threadIdx.x == 0) small_cnt[j] = -1;
-        return;
+    const int64_t j = ONE_PASS ? (int64_t)blockIdx.x : list[blockIdx.x];
+    if constexpr (ONE_PASS) {
+        if (small_flops[j] > (int64_t)SMALL_ROOM) {
+            if (threadIdx.x == 0) small_cnt[j] = -1;
+            return;
+        }
     }
     const ACC ident = (ACC)sr.identity();
     for (int s = threadIdx.x; s < SLOTS; s += THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
@@ -688,7 +690,7 @@ num_block_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
         sr.atomic(&vals[h], t);
     });
     __syncthreads();
-    const int64_t pC = small_cnt ? j * (int64_t)SMALL_ROOM : Cp[j];
+    const int64_t pC = ONE_PASS ? j * (int64_t)SMALL_ROOM : Cp[j];
     for (int s = threadIdx.x; s < SLOTS; s += THREADS) {
         const int32_t key = keys[s];
         if (key != HASH_EMPTY) {
@@ -697,7 +699,7 @@ num_block_kernel(S sr, int64_t nlist, const int64_t *__restrict__ list, SpView A
             Cx[pC + pos] = (Z)vals[s];
         }
     }
-    if (small_cnt) {
+    if constexpr (ONE_PASS) {
         __syncthreads();
         if (threadIdx.x == 0) small_cnt[j] = cursor;
     }
@@ -2363,7 +2365,7 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         GBA_OK(slab_x.alloc((size_t)nvec * SMALL_ROOM * zsize));
         GBA_OK(with_semiring(c, [&](auto sr) -> gba_info {
             using S = decltype(sr); using Z = typename S::z_t; using ACC = typename S::acc_t;
-            auto k = num_block_kernel<S, NUM_BLK2_SLOTS, NUM_BLK2_THREADS>;
+            auto k = num_block_kernel<S, NUM_BLK2_SLOTS, NUM_BLK2_THREADS, true>;
             const size_t lds = (size_t)NUM_BLK2_SLOTS * (sizeof(ACC) + 4);
             GBA_OK(set_lds(k, lds));
             hipLaunchKernelGGL(k, dim3((unsigned)nvec), dim3(NUM_BLK2_THREADS), lds, st, sr, nvec, (const int64_t *)nullptr,
