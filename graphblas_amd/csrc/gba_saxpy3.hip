@@ -997,7 +997,7 @@ static constexpr int PANEL_SEGCAP = PANEL_THREADS;                    // runs qu
 static constexpr int PANEL_UNROLL_MAX = 8;
 // two windows per wave in flight (the loads of one issued before the other is consumed)?
 static constexpr bool SYM_PANEL_PIPELINE = false, NUM_PANEL_PIPELINE = false;
-static constexpr int SYM_PANEL_UNROLL = 4, NUM_PANEL_UNROLL = 2;            // products in flight per thread
+static constexpr int SYM_PANEL_UNROLL = 8, NUM_PANEL_UNROLL = 4;            // products in flight per thread
 static constexpr int PANEL_T_BITS = 24;
 static constexpr int64_t PANEL_MAX_DEG = (int64_t)1 << PANEL_T_BITS;
 static constexpr int64_t PANEL_MAX_WIDTH = (int64_t)1 << 20;          // (SEGCAP-1) runs of this length stay below 2^32
@@ -1076,7 +1076,7 @@ __device__ inline int64_t first_ge(const int32_t *__restrict__ X, int64_t lo, in
 // needs; apply(i[], payload[], ok[]) consumes a batch of PANEL_UNROLL.  Needs a barrier between the last
 // append and the call; ends on a barrier with the queue empty.
 template <int PANEL_UNROLL, bool PANEL_PIPELINE, class Load, class Apply>
-__device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSegs *S, Load load, Apply apply) {
+__device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSegs *S, Load load, Apply apply, bool take_turns) {
     constexpr int QPT = PANEL_SEGCAP / PANEL_THREADS;      // queue entries per thread in the scan
     static_assert(QPT * PANEL_THREADS == PANEL_SEGCAP && PANEL_SEGCAP <= 64 * 64, "two 64-way steps find a run");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1101,10 +1101,10 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
     GBA_TICK(tke1);
     GBA_TOCK(S, 2, tke0, tke1);
     const int32_t *__restrict__ Ai = A.i32;
-    // The products are cut into windows of WIN consecutive ones.  With few windows (a numeric panel has
-    // a few dozen) the waves take them from an LDS counter as they get free -- the time per window
-    // varies with the hash probes and the cache misses it meets; with many (symbolic panels) every
-    // wave owns a contiguous slab.  A wave bisects the prefix sums for the run holding the first product
+    // The products are cut into windows of WIN consecutive ones.  With take_turns and few windows (a numeric
+    // panel has a few dozen) the waves take them from an LDS counter as they get free -- the time per window
+    // varies with the hash probes and the cache misses it meets; otherwise (many windows, or the symbolic
+    // sweep, whose windows cost the same) every wave owns a contiguous slab.  A wave bisects the prefix sums for the run holding the first product
     // of a window (uniform address: broadcast reads; inside a slab the next window's run follows from
     // the marks).  The runs that START inside the window are read 64 at a time (one conflict-free LDS
     // read), marked in WIN bits, and a product's run is the window's first run plus the number of
@@ -1113,7 +1113,7 @@ __device__ inline void panel_expand(const SpView &A, int64_t pB0, int n, PanelSe
     constexpr int NWAVES = PANEL_THREADS / 64;
     const uint32_t nwin = (uint32_t)(((uint64_t)T + WIN - 1) / WIN);
     {
-        const bool dynamic = nwin < (uint32_t)(NWAVES * 16);
+        const bool dynamic = take_turns && nwin < (uint32_t)(NWAVES * 16);
         const uint32_t per = (nwin + NWAVES - 1) / NWAVES;
         uint32_t win = (uint32_t)wv * per;
         const uint32_t win_end = (win + per < nwin) ? win + per : nwin;
@@ -1287,7 +1287,7 @@ __device__ inline void group_first_ge(const int32_t *__restrict__ X, bool act, i
 template <int PANEL_UNROLL, bool PANEL_PIPELINE, class Load, class Apply>
 __device__ inline void panel_walk_groups(const SpView &A, const SpView &B, int64_t pB0, int64_t deg, int64_t ibeg,
                                          int64_t pend, int64_t iend, bool first, const PanelCursors &pc, PanelSegs *S,
-                                         Load load, Apply apply) {
+                                         Load load, Apply apply, bool take_turns) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int32_t *__restrict__ Ai = A.i32;
     int lgG = 6;
@@ -1341,7 +1341,7 @@ __device__ inline void panel_walk_groups(const SpView &A, const SpView &B, int64
     GBA_TICK(tk2);
     GBA_TOCK(S, 0, tk0, tk1); GBA_TOCK(S, 1, tk1, tk2);
     const int ns = S->nseg;
-    if (ns > 0) panel_expand<PANEL_UNROLL, PANEL_PIPELINE>(A, pB0, ns, S, load, apply);
+    if (ns > 0) panel_expand<PANEL_UNROLL, PANEL_PIPELINE>(A, pB0, ns, S, load, apply, take_turns);
     else __syncthreads();
 }
 
@@ -1356,9 +1356,9 @@ __device__ inline void panel_walk_groups(const SpView &A, const SpView &B, int64
 template <int PANEL_UNROLL, bool PANEL_PIPELINE, class Load, class Apply>
 __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0, int64_t deg, int64_t ibeg,
                                   int64_t pend, int64_t iend, bool first, const PanelCursors &pc, PanelSegs *S,
-                                  Load load, Apply apply) {
+                                  Load load, Apply apply, bool take_turns) {
     if (deg * 2 <= PANEL_THREADS) {
-        panel_walk_groups<PANEL_UNROLL, PANEL_PIPELINE>(A, B, pB0, deg, ibeg, pend, iend, first, pc, S, load, apply);
+        panel_walk_groups<PANEL_UNROLL, PANEL_PIPELINE>(A, B, pB0, deg, ibeg, pend, iend, first, pc, S, load, apply, take_turns);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1481,7 +1481,7 @@ __device__ inline void panel_walk(const SpView &A, const SpView &B, int64_t pB0,
         const int ns = S->nseg;
         const bool last = t0 + PANEL_STEP >= deg;
         if (ns > 0 && (ns > PANEL_SEGCAP - PANEL_STEP || last)) {
-            panel_expand<PANEL_UNROLL, PANEL_PIPELINE>(A, pB0, ns, S, load, apply);
+            panel_expand<PANEL_UNROLL, PANEL_PIPELINE>(A, pB0, ns, S, load, apply, take_turns);
             if (S->overflow) return;
         } else {
             __syncthreads();                                    // everyone has read nseg before the next append
@@ -1580,7 +1580,7 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                         const uint32_t o = (uint32_t)(i[u] - base);
                         atomicOr(&bm[o >> 5], 1u << (o & 31));
                     }
-                });
+                }, false);
             // count in index order: each thread owns SYM_WORDS_PER_THREAD consecutive words, read once with 16-byte
             // LDS loads (conflict-free at this stride); the packed sum carries the entries (low 21 bits: a panel has
             // at most 2^20) and the non-empty words (above) of the slice
@@ -1943,7 +1943,7 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                         }
                         if (slot >= 0) sr.atomic(&vals[slot], t[u]); else Q.overflow = 1;
                     }
-                });
+                }, true);
             if (!ranked && Q.overflow) {                 // uniform: raised before the barrier that ended the walk
                 width = (width > 1) ? (width >> 1) : 1;
                 shrink++;
