@@ -2568,7 +2568,9 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
             numwork = nw.as<int64_t>();
         }
         // products per thread stay bounded: by flops a vector may need a larger bin than its entry count asks for
-        GBA_OK(build_bins(nvec, numwork, false, BinLimits{NUM_WAVE_MAX, NUM_BLK1_MAX, NUM_BLK2_MAX}, &P.num,
+        // (with the panel kernel at hand the second block bin stays empty: the panel kernel emits those vectors in a
+        // third of the time)
+        GBA_OK(build_bins(nvec, numwork, false, BinLimits{NUM_WAVE_MAX, NUM_BLK1_MAX, (P.use_panels && P.maxdeg < PANEL_MAX_DEG) ? NUM_BLK1_MAX : NUM_BLK2_MAX}, &P.num,
                           vflops.as<int64_t>(), BinLimits{2048, 16384, 65536}));
     }
     if (P.num.count[BIN_GLOBAL] > 0 && P.maxdeg == 0) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
