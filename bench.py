@@ -219,7 +219,7 @@ def main():
                          **measured_counters(f"RMAT-{args.scale} ef={args.edge_factor}", names[k]),
                          # what holds the kernel below the HBM line (in-kernel stopwatch build and instruction counters)
                          "limiter": "per-panel chain of dependent phases (search 20 %, run queue 5 %, windows of products "
-                                    "55 %, emit 10 %) in one 1024-thread workgroup per CU; 146 VALU + 84 scalar "
+                                    "55 %, emit 10 %) in one 1024-thread workgroup per CU; 148 VALU + 85 scalar "
                                     "instructions per 64 products",
                          "avg_launch_ms": round(float(k_ms), 3), "algorithmic_bytes_per_launch": int(k_bytes),
                          "streaming_model_GBps": round(streamed, 2),
