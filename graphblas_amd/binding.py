@@ -45,11 +45,11 @@ class Type:
 NP_TYPES = {
     Type.BOOL: np.bool_, Type.INT8: np.int8, Type.UINT8: np.uint8, Type.INT16: np.int16, Type.UINT16: np.uint16,
     Type.INT32: np.int32, Type.UINT32: np.uint32, Type.INT64: np.int64, Type.UINT64: np.uint64,
-    Type.FP32: np.float32, Type.FP64: np.float64,
+    Type.FP32: np.float32, Type.FP64: np.float64, Type.FC32: np.complex64, Type.FC64: np.complex128,
 }
 TYPE_OF_NP = {np.dtype(v): k for k, v in NP_TYPES.items()}
 TYPE_NAMES = {"BOOL": 1, "INT8": 2, "UINT8": 3, "INT16": 4, "UINT16": 5, "INT32": 6, "UINT32": 7, "INT64": 8,
-              "UINT64": 9, "FP32": 10, "FP64": 11}
+              "UINT64": 9, "FP32": 10, "FP64": 11, "FC32": 12, "FC64": 13}
 
 
 class Op:

@@ -189,6 +189,11 @@ gba_info saxpy4(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const C
 gba_info saxpy5(gba_matrix *C, const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep);
 gba_info saxbit(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
                 const gba_matrix *A, const gba_matrix *B, const Canon &c, gba_report *rep);
+// built-in complex semirings (gba_jit.hip): compiled at run time like a user-defined type
+gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum, const gba_semiring *s,
+                     const gba_matrix *A, bool A_tran, const gba_matrix *B, bool B_tran, bool flipxy,
+                     bool C_replace, bool Mask_comp, bool Mask_struct, gba_report *report);
+inline bool is_complex_type(int t) { return t == GBA_FC32 || t == GBA_FC64; }
 gba_info transpose(gba_matrix *AT, const gba_matrix *A);
 gba_info to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owned);   // bitmap/full -> sparse copy
 // hypersparse -> sparse view over all vdim vectors (new p; i and x shared with X)

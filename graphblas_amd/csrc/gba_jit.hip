@@ -254,6 +254,150 @@ gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, con
     return info;
 }
 
+// ------------------------------------------------------------------ complex --
+// The built-in complex semirings -- (PLUS, TIMES, ANY) x (FIRST, SECOND, PAIR, PLUS, MINUS, RMINUS, TIMES,
+// DIV, RDIV) over GxB_FC32 and GxB_FC64, Source/Factories/GB_AxB_factory.c:46-243 with GB_COMPLEX and
+// GB_AxB_type_factory.c:100-154 -- take the road of the user-defined types: a 16-byte value has no atomic
+// update, and the per-entry dot product needs none.  The operators are written out as source for hipRTC:
+// x*y, x+y, x-y as the C99 operators of Source/Shared/GB_complex.h:237-246 compile them (products and
+// sums in the type's own precision, no fused multiply-add, the infinity recovery of C99 Annex G.5.1 when
+// both parts come out NaN), and the library's own division, GB_FC64_div / GB_FC32_div
+// (Source/GB_math.h:301-389: Smith's three cases; single complex divides in double and rounds).
+static std::string complex_type_defn(bool dbl) {
+    return dbl ? "typedef struct { double re ; double im ; } gba_fc64 ;" : "typedef struct { float re ; float im ; } gba_fc32 ;";
+}
+
+static bool complex_op_source(int op, bool dbl, std::string *name, std::string *defn) {
+    const std::string T = dbl ? "gba_fc64" : "gba_fc32", R = dbl ? "double" : "float";
+    const char *tag = nullptr; std::string body;
+    switch (op) {
+        case GBA_FIRST: case GBA_ANY: tag = "first"; body = "const " + T + " a = *x ; *z = a ;"; break;
+        case GBA_SECOND: tag = "second"; body = "const " + T + " b = *y ; *z = b ;"; break;
+        case GBA_PAIR:   tag = "pair";   body = "z->re = 1 ; z->im = 0 ;"; break;
+        case GBA_PLUS:   tag = "plus";   body = "const " + T + " a = *x, b = *y ; z->re = a.re + b.re ; z->im = a.im + b.im ;"; break;
+        case GBA_MINUS:  tag = "minus";  body = "const " + T + " a = *x, b = *y ; z->re = a.re - b.re ; z->im = a.im - b.im ;"; break;
+        case GBA_RMINUS: tag = "rminus"; body = "const " + T + " a = *x, b = *y ; z->re = b.re - a.re ; z->im = b.im - a.im ;"; break;
+        case GBA_TIMES:  tag = "times";
+            body = R + " a = x->re, b = x->im, c = y->re, d = y->im ;\n"
+                   "    const " + R + " ac = a * c, bd = b * d, ad = a * d, bc = b * c ;\n"
+                   "    " + R + " re = ac - bd, im = ad + bc ;\n"
+                   "    if (__builtin_isnan (re) && __builtin_isnan (im))\n"
+                   "    {\n"
+                   "        int recalc = 0 ;\n"
+                   "        if (__builtin_isinf (a) || __builtin_isinf (b))\n"
+                   "        {\n"
+                   "            a = __builtin_copysign (__builtin_isinf (a) ? 1.0 : 0.0, a) ; b = __builtin_copysign (__builtin_isinf (b) ? 1.0 : 0.0, b) ;\n"
+                   "            if (__builtin_isnan (c)) c = __builtin_copysign (0.0, c) ;\n"
+                   "            if (__builtin_isnan (d)) d = __builtin_copysign (0.0, d) ;\n"
+                   "            recalc = 1 ;\n"
+                   "        }\n"
+                   "        if (__builtin_isinf (c) || __builtin_isinf (d))\n"
+                   "        {\n"
+                   "            c = __builtin_copysign (__builtin_isinf (c) ? 1.0 : 0.0, c) ; d = __builtin_copysign (__builtin_isinf (d) ? 1.0 : 0.0, d) ;\n"
+                   "            if (__builtin_isnan (a)) a = __builtin_copysign (0.0, a) ;\n"
+                   "            if (__builtin_isnan (b)) b = __builtin_copysign (0.0, b) ;\n"
+                   "            recalc = 1 ;\n"
+                   "        }\n"
+                   "        if (!recalc && (__builtin_isinf (ac) || __builtin_isinf (bd) || __builtin_isinf (ad) || __builtin_isinf (bc)))\n"
+                   "        {\n"
+                   "            if (__builtin_isnan (a)) a = __builtin_copysign (0.0, a) ;\n"
+                   "            if (__builtin_isnan (b)) b = __builtin_copysign (0.0, b) ;\n"
+                   "            if (__builtin_isnan (c)) c = __builtin_copysign (0.0, c) ;\n"
+                   "            if (__builtin_isnan (d)) d = __builtin_copysign (0.0, d) ;\n"
+                   "            recalc = 1 ;\n"
+                   "        }\n"
+                   "        if (recalc)\n"
+                   "        {\n"
+                   "            re = (" + R + ") __builtin_huge_val () * (a * c - b * d) ;\n"
+                   "            im = (" + R + ") __builtin_huge_val () * (a * d + b * c) ;\n"
+                   "        }\n"
+                   "    }\n"
+                   "    z->re = re ; z->im = im ;";
+            break;
+        case GBA_DIV: case GBA_RDIV: {
+            tag = (op == GBA_DIV) ? "div" : "rdiv";
+            const std::string num = (op == GBA_DIV) ? "x" : "y", den = (op == GBA_DIV) ? "y" : "x";
+            body = "const double xr = " + num + "->re, xi = " + num + "->im, yr = " + den + "->re, yi = " + den + "->im ;\n"
+                   "    double zr, zi ;\n"
+                   "    if (yi == 0) { zr = xr / yr ; zi = xi / yr ; }\n"
+                   "    else if (yr == 0) { zr = xi / yi ; zi = -xr / yi ; }\n"
+                   "    else if (__builtin_isinf (yi) && __builtin_isinf (yr))\n"
+                   "    {\n"
+                   "        const double r = (__builtin_signbit (yr) == __builtin_signbit (yi)) ? 1 : -1, d = yr + r * yi ;\n"
+                   "        zr = (xr + xi * r) / d ; zi = (xi - xr * r) / d ;\n"
+                   "    }\n"
+                   "    else if (__builtin_fabs (yr) >= __builtin_fabs (yi))\n"
+                   "    {\n"
+                   "        const double r = yi / yr, d = yr + r * yi ;\n"
+                   "        zr = (xr + xi * r) / d ; zi = (xi - xr * r) / d ;\n"
+                   "    }\n"
+                   "    else\n"
+                   "    {\n"
+                   "        const double r = yr / yi, d = r * yr + yi ;\n"
+                   "        zr = (xr * r + xi) / d ; zi = (xi * r - xr) / d ;\n"
+                   "    }\n"
+                   "    z->re = (" + R + ") zr ; z->im = (" + R + ") zi ;";
+            break;
+        }
+        default: return false;
+    }
+    *name = T + "_" + tag;
+    *defn = "void " + *name + " (" + T + " *z, const " + T + " *x, const " + T + " *y)\n{\n    " + body + "\n}";
+    return true;
+}
+
+gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum, const gba_semiring *s,
+                     const gba_matrix *A, bool A_tran, const gba_matrix *B, bool B_tran, bool flipxy,
+                     bool C_replace, bool Mask_comp, bool Mask_struct, gba_report *report) {
+    GBA_OK(require_init());
+    if (!C || !A || !B || !s) GBA_FAIL(GBA_NULL_POINTER, "C, A, B or the semiring is NULL");
+    const int zt = s->ztype;
+    const bool dbl = (zt == GBA_FC64);
+    int mult = s->mult, add = s->add;
+    mult = flip_binop(mult, &flipxy);
+    if (flipxy) GBA_FAIL(GBA_NOT_IMPLEMENTED, "multiplier %d cannot be flipped", mult);
+    if (!(add == GBA_PLUS || add == GBA_TIMES || add == GBA_ANY))
+        GBA_FAIL(GBA_DOMAIN_MISMATCH, "monoid %d has no complex form (PLUS, TIMES and ANY do)", add);
+    // the operands the multiplier reads, the product and C all have the semiring's complex type: casts between
+    // complex and real values are left to the CPU library
+    const bool a_read = !(mult == GBA_SECOND || mult == GBA_PAIR), b_read = !(mult == GBA_FIRST || mult == GBA_PAIR);
+    if (mult != GBA_PAIR && ((a_read && s->xtype != zt) || (b_read && s->ytype != zt)))
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "complex monoid with a multiplier over types %d, %d", s->xtype, s->ytype);
+    if (C->type != zt || A->type != zt || B->type != zt)
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "complex semiring of type %d with C, A, B of types %d, %d, %d (typecast)", zt, C->type, A->type, B->type);
+    if (C->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_NOT_IMPLEMENTED, "C must be a device view (mem == GBA_MEM_DEVICE)");
+    if (M && !Mask_struct && !is_real_type(M->type)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "valued mask of type %d", M->type);
+    std::string add_name, add_defn, mult_name, mult_defn, acc_name, acc_defn;
+    if (!complex_op_source(add, dbl, &add_name, &add_defn) || !complex_op_source(mult, dbl, &mult_name, &mult_defn))
+        GBA_FAIL(GBA_DOMAIN_MISMATCH, "operator %d / %d has no complex form", add, mult);
+    const bool has_accum = accum && accum->op != GBA_NOP;
+    if (has_accum) {
+        if (accum->type != zt) GBA_FAIL(GBA_NOT_IMPLEMENTED, "accumulator of type %d on a complex C (typecast)", accum->type);
+        if (!complex_op_source(accum->op, dbl, &acc_name, &acc_defn)) GBA_FAIL(GBA_DOMAIN_MISMATCH, "accumulator %d has no complex form", accum->op);
+    }
+    const std::string tdefn = complex_type_defn(dbl);
+    gba_user_semiring us{};
+    us.type_name = dbl ? "gba_fc64" : "gba_fc32"; us.type_defn = tdefn.c_str(); us.type_size = type_size(zt);
+    us.add_name = add_name.c_str(); us.add_defn = add_defn.c_str();
+    us.mult_name = mult_name.c_str(); us.mult_defn = mult_defn.c_str();
+
+    struct Owned { std::vector<void *> v; ~Owned() { for (void *p : v) gba_free(p); } } own;
+    gba_matrix Av, Bv, Mv, Cv = *C;
+    if (A->mem == GBA_MEM_HOST) GBA_OK(stage_to_device(A, &Av, own.v)); else Av = *A;
+    if (B->mem == GBA_MEM_HOST) GBA_OK(stage_to_device(B, &Bv, own.v)); else Bv = *B;
+    if (M) { if (M->mem == GBA_MEM_HOST) GBA_OK(stage_to_device(M, &Mv, own.v)); else Mv = *M; }
+    Av.type = Bv.type = Cv.type = GBA_UDT;
+    gba_descriptor d{};
+    d.out = C_replace ? GBA_REPLACE : GBA_DEFAULT;
+    d.mask = Mask_comp ? (Mask_struct ? GBA_COMP_STRUCTURE : GBA_COMP) : (Mask_struct ? GBA_STRUCTURE : GBA_DEFAULT);
+    d.in0 = A_tran ? GBA_TRAN : GBA_DEFAULT; d.in1 = B_tran ? GBA_TRAN : GBA_DEFAULT;
+    const gba_info info = mxm_udt(&Cv, M ? &Mv : nullptr, has_accum ? acc_name.c_str() : nullptr, has_accum ? acc_defn.c_str() : nullptr,
+                                  &us, &Av, &Bv, &d, report);
+    Cv.type = zt;
+    *C = Cv;                    // on failure mxm_udt leaves the view as it was
+    return info;
+}
+
 }  // namespace gba
 
 extern "C" gba_info gba_mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,

@@ -1062,6 +1062,9 @@ static gba_info mxm_driver_sparse_C(Call k, gba_report *report, bool select_only
 // A C that comes in hypersparse goes back hypersparse: the kernels work on its sparse form (a pointer per vector),
 // and the list of non-empty vectors is rebuilt from the result.
 static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
+    if (is_complex_type(k.semiring.ztype) && !select_only)
+        return mxm_complex(k.C, k.M, k.has_accum ? &k.accum : nullptr, &k.semiring, k.A_in, k.A_transpose, k.B_in,
+                           k.B_transpose, k.flipxy, k.C_replace, k.Mask_comp, k.Mask_struct, report);
     const bool C_was_hyper = k.C && is_hyper(k.C);
     const gba_info info = mxm_driver_sparse_C(k, report, select_only);
     if (info != GBA_SUCCESS || !C_was_hyper || select_only || !is_sparse(k.C) || k.C->mem != GBA_MEM_DEVICE) return info;

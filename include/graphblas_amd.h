@@ -131,7 +131,7 @@ typedef struct gba_matrix {
 #define GBA_FLIP(i) (-(i) - 2)          /* Source/Template/GB_zombie.h */
 
 /* built-in semiring: z = add-reduce over k of mult(x = A(i,k), y = B(k,j)).
- * gba_mxm / gba_mxv / gba_vxm take built-in operators only; user-defined types and
+ * gba_mxm / gba_mxv / gba_vxm take built-in operators only (real and complex); user-defined types and
  * operators (GBA_USER_BINOP) go through gba_mxm_udt, which compiles them with hipRTC. */
 typedef struct gba_semiring {
     gba_opcode add;      /* monoid operator; its type is ztype            */
@@ -232,8 +232,14 @@ void     gba_matrix_free_content(gba_matrix *A);
  * A sparse mask far costlier than the product is left out of the multiply and
  * applied in the write-back (Source/GB_AxB_saxpy3_slice_balanced.c:309-403);
  * report->mask_applied tells which happened.
+ * The built-in complex semirings -- (PLUS, TIMES, ANY) x (FIRST, SECOND, PAIR,
+ * PLUS, MINUS, RMINUS, TIMES, DIV, RDIV) over GBA_FC32 / GBA_FC64,
+ * Source/Factories/GB_AxB_factory.c:46-243 -- are taken when A, B, C and the
+ * accumulator all have the semiring's type; they run on the road of
+ * gba_mxm_udt (operators compiled by hipRTC, one dot product per entry) and
+ * share its limits on accum / mask / C combinations.
  * Returns GBA_NOT_IMPLEMENTED for valid calls outside the device path
- * (complex types, user-defined ops -- see gba_mxm_udt --, ...):
+ * (casts to or from complex, user-defined ops -- see gba_mxm_udt --, ...):
  * the caller keeps the CPU library for those, like the GB_cuda_*_branch test
  * in Source/GB_AxB_dot.c:189-197. */
 gba_info gba_mxm(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,

@@ -25,6 +25,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <math.h>
+#include <complex.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -90,6 +91,38 @@ DEF_BIN(f_lor_BOOL, bool, bool, x || y) DEF_BIN(f_land_BOOL, bool, bool, x && y)
 DEF_BIN(f_eq_BOOL, bool, bool, x == y) DEF_BIN(f_gt_BOOL, bool, bool, x > y) DEF_BIN(f_lt_BOOL, bool, bool, x < y)
 DEF_BIN(f_ge_BOOL, bool, bool, x >= y) DEF_BIN(f_le_BOOL, bool, bool, x <= y)
 
+/* complex: the C99 operators of the non-MSVC branch of Source/Shared/GB_complex.h:237-246 (x*y, x+y, x-y on
+ * float/double complex), PAIR = 1+0i (Source/Factories/GB_ops_template.h, GxB_CMPLX (1,0)), and the
+ * library's own division -- never the compiler's: GB_FC64_div, three cases after R. L. Smith, ACM Algorithm
+ * 116 (Source/GB_math.h:301-340); single complex divides in double and rounds (Source/GB_math.h:379-389).
+ * The semirings offered are (PLUS, TIMES, ANY) x (FIRST, SECOND, PAIR, PLUS, MINUS, RMINUS, TIMES, DIV,
+ * RDIV), Source/Factories/GB_AxB_factory.c:46-243 with GB_COMPLEX, GB_AxB_type_factory.c:100-154. */
+typedef float _Complex fc32_t;
+typedef double _Complex fc64_t;
+static fc64_t fc64_div(fc64_t x, fc64_t y) {
+    const double xr = creal(x), xi = cimag(x), yr = creal(y), yi = cimag(y);
+    const int yr_class = fpclassify(yr), yi_class = fpclassify(yi);
+    if (yi_class == FP_ZERO) return CMPLX(xr / yr, xi / yr);
+    if (yr_class == FP_ZERO) return CMPLX(xi / yi, -xr / yi);
+    if (yi_class == FP_INFINITE && yr_class == FP_INFINITE) {
+        const double r = (signbit(yr) == signbit(yi)) ? 1 : -1, d = yr + r * yi;
+        return CMPLX((xr + xi * r) / d, (xi - xr * r) / d);
+    }
+    if (fabs(yr) >= fabs(yi)) { const double r = yi / yr, d = yr + r * yi; return CMPLX((xr + xi * r) / d, (xi - xr * r) / d); }
+    const double r = yr / yi, d = r * yr + yi;
+    return CMPLX((xr * r + xi) / d, (xi * r - xr) / d);
+}
+static fc32_t fc32_div(fc32_t x, fc32_t y) {
+    const fc64_t z = fc64_div(CMPLX((double)crealf(x), (double)cimagf(x)), CMPLX((double)crealf(y), (double)cimagf(y)));
+    return CMPLXF((float)creal(z), (float)cimag(z));
+}
+#define DEF_COMPLEX(TAG, T, ONE, DIV) \
+    DEF_BIN(f_first_##TAG, T, T, x) DEF_BIN(f_second_##TAG, T, T, y) DEF_BIN(f_pair_##TAG, T, T, ONE) \
+    DEF_BIN(f_plus_##TAG, T, T, x + y) DEF_BIN(f_minus_##TAG, T, T, x - y) DEF_BIN(f_rminus_##TAG, T, T, y - x) \
+    DEF_BIN(f_times_##TAG, T, T, x * y) DEF_BIN(f_div_##TAG, T, T, DIV(x, y)) DEF_BIN(f_rdiv_##TAG, T, T, DIV(y, x))
+DEF_COMPLEX(FC32, fc32_t, CMPLXF(1, 0), fc32_div)
+DEF_COMPLEX(FC64, fc64_t, CMPLX(1, 0), fc64_div)
+
 typedef void (*binfn)(void *, const void *, const void *);
 
 size_t orc_type_size(int code) {
@@ -123,6 +156,16 @@ static binfn lookup_binop(int op, int type) {
             case GBA_GE: return f_ge_BOOL; case GBA_LE: return f_le_BOOL;
             default: return NULL;
         }
+    }
+    if (type == GBA_FC32 || type == GBA_FC64) {
+#define CPLX(fname) return type == GBA_FC32 ? f_##fname##_FC32 : f_##fname##_FC64
+        switch (op) {
+            case GBA_FIRST: case GBA_ANY: CPLX(first);   case GBA_SECOND: CPLX(second);   case GBA_PAIR: CPLX(pair);
+            case GBA_PLUS: CPLX(plus);   case GBA_MINUS: CPLX(minus);   case GBA_RMINUS: CPLX(rminus);
+            case GBA_TIMES: CPLX(times); case GBA_DIV: CPLX(div);       case GBA_RDIV: CPLX(rdiv);
+            default: return NULL;
+        }
+#undef CPLX
     }
     switch (op) {
         case GBA_FIRST: NUM_SWITCH(op, first)   case GBA_SECOND: NUM_SWITCH(op, second)

@@ -6,8 +6,8 @@
  *      GxB_Vector_unpack_CSC/Bitmap/Full (Include/GraphBLAS.h:9869-10158; O(1): 9298-9303);
  *   2. gba_mxm / gba_mxv / gba_vxm run the multiply on the MI355X (include/graphblas_amd.h);
  *   3. everything is packed back (GxB_Matrix_pack_*, GxB_Vector_pack_*, 9342-9760).
- * A call the device path does not take (user-defined or complex types, iso-valued operands, an operator
- * without a built-in code, GBA_NOT_IMPLEMENTED from the library) goes to the next definition of the same
+ * A call the device path does not take (user-defined types, casts to or from complex, iso-valued operands,
+ * an operator without a built-in code, GBA_NOT_IMPLEMENTED from the library) goes to the next definition of the same
  * symbol, dlsym (RTLD_NEXT, ...): the CPU library, with its arguments untouched.
  *
  * Memory: the handles hold host arrays of the allocator given to GxB_init.  A, B and the mask are handed
@@ -51,10 +51,13 @@ static const struct { const char *name ; gba_opcode code ; } shim_ops [ ] = {
     {"FIRSTJ1", GBA_FIRSTJ1}, {"SECONDI", GBA_SECONDI}, {"SECONDI1", GBA_SECONDI1}, {"SECONDJ", GBA_SECONDJ},
     {"SECONDJ1", GBA_SECONDJ1} } ;
 
-/* GrB_Type_Code of a built-in real type -> gba_type (the codes agree for BOOL .. FP64) */
+/* GrB_Type_Code of a built-in type -> gba_type (the codes agree for BOOL .. FP64; the complex types carry
+ * GxB codes, Include/GraphBLAS.h:4093-4094) */
 static bool shim_type (gba_type *t, int32_t code)
 {
-    if (code < GrB_BOOL_CODE || code > GrB_FP64_CODE) return (false) ;      /* user-defined, complex */
+    if (code == GxB_FC32_CODE) { (*t) = GBA_FC32 ; return (true) ; }
+    if (code == GxB_FC64_CODE) { (*t) = GBA_FC64 ; return (true) ; }
+    if (code < GrB_BOOL_CODE || code > GrB_FP64_CODE) return (false) ;      /* user-defined */
     (*t) = (gba_type) code ;
     return (true) ;
 }
@@ -275,6 +278,7 @@ static size_t shim_type_size (gba_type t)
         case GBA_BOOL : case GBA_INT8 : case GBA_UINT8 : return (1) ;
         case GBA_INT16 : case GBA_UINT16 : return (2) ;
         case GBA_INT32 : case GBA_UINT32 : case GBA_FP32 : return (4) ;
+        case GBA_FC64 : return (16) ;
         default : return (8) ;
     }
 }

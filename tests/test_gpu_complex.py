@@ -1,0 +1,172 @@
+"""GPU parity for the built-in complex semirings through gba_mxm / gba_mxv / gba_vxm:
+(PLUS, TIMES, ANY) x (FIRST, SECOND, PAIR, PLUS, MINUS, RMINUS, TIMES, DIV, RDIV) over GxB_FC32 and GxB_FC64
+(Source/Factories/GB_AxB_factory.c:46-243 with GB_COMPLEX, GB_AxB_type_factory.c:100-154).
+
+The device evaluates every entry as one dot product in increasing k, which is the order of the definition
+restated in oracle.mxm_spec, with the same unfused multiply and add: values are compared bit for bit.
+The reference holds no runnable known answers for its complex semirings (its test suite is MATLAB-only):
+parity of these operators is pinned by the oracle's restatement of GB_complex.h / GB_math.h alone."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from graphblas_amd import Matrix, Type, GrbError, Info
+from oracle import oracle
+from util import assert_dense_same
+
+pytestmark = pytest.mark.gpu
+NAME = {Type.FC32: "FC32", Type.FC64: "FC64"}
+
+
+def _rand(n, m, density, seed, t=Type.FC64, by_row=True):
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, m, density=density, random_state=rng, format="csr").astype(np.complex128)
+    k = len(S.data)
+    S.data = rng.uniform(0.5, 2.0, k) + 1j * rng.uniform(-2.0, 2.0, k)
+    return Matrix.from_scipy(S, type=t, by_row=by_row)
+
+
+def _mask(n, m, density, seed):
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, m, density=density, random_state=rng, format="csr")
+    S.data = rng.integers(0, 2, len(S.data)).astype(np.float64)
+    return Matrix.from_scipy(S, type=Type.INT8)
+
+
+@pytest.mark.parametrize("t", [Type.FC32, Type.FC64])
+@pytest.mark.parametrize("mult", ["FIRST", "SECOND", "PAIR", "PLUS", "MINUS", "RMINUS", "TIMES", "DIV", "RDIV"])
+@pytest.mark.parametrize("add", ["PLUS", "TIMES", "ANY"])
+def test_every_complex_semiring(gba, add, mult, t):
+    n = 48
+    A, B = _rand(n, 40, 0.12, 1, t), _rand(40, n, 0.12, 2, t)
+    C0 = Matrix.sparse_empty(n, n, t)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    sr = f"{add}_{mult}_{NAME[t]}"
+    gba.mxm(dC, None, None, sr, dA, dB, None)
+    p, v = oracle.mxm_spec(C0, None, None, sr, A, B)
+    got = dC.to_host()
+    assert got.type == t
+    # ANY may keep any of the terms: the device and the definition both keep the first in k
+    assert_dense_same(got, p, v, exact=True, what=sr)
+
+
+@pytest.mark.parametrize("desc", ["", "T0", "T1", "T0T1"])
+@pytest.mark.parametrize("fmt", ["rrr", "ccc", "rcr", "crc"])
+def test_complex_transposes_and_formats(gba, desc, fmt):
+    n = 40
+    A = _rand(n, n, 0.1, 3, by_row=fmt[1] == "r")
+    B = _rand(n, n, 0.1, 4, by_row=fmt[2] == "r")
+    C0 = Matrix.sparse_empty(n, n, Type.FC64, by_row=fmt[0] == "r")
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    gba.mxm(dC, None, None, "PLUS_TIMES_FC64", dA, dB, desc)
+    p, v = oracle.mxm_spec(C0, None, None, "PLUS_TIMES_FC64", A, B, desc)
+    got = dC.to_host()
+    assert got.is_csc == C0.is_csc
+    assert_dense_same(got, p, v, exact=True, what=f"{desc}/{fmt}")
+
+
+@pytest.mark.parametrize("desc", ["S", "SC", "", "C", "RS", "RSC"])
+def test_complex_masked(gba, desc):
+    n = 50
+    A, B = _rand(n, n, 0.1, 5), _rand(n, n, 0.1, 6)
+    M = _mask(n, n, 0.3, 7)
+    C0 = Matrix.sparse_empty(n, n, Type.FC64)
+    dA, dB, dM, dC = A.to_device(), B.to_device(), M.to_device(), C0.to_device()
+    gba.mxm(dC, dM, None, "PLUS_TIMES_FC64", dA, dB, desc)
+    p, v = oracle.mxm_spec(C0, M, None, "PLUS_TIMES_FC64", A, B, desc)
+    assert_dense_same(dC.to_host(), p, v, exact=True, what=desc)
+
+
+@pytest.mark.parametrize("accum", ["PLUS_FC64", "TIMES_FC64", "SECOND_FC64", "MINUS_FC64", "DIV_FC64"])
+@pytest.mark.parametrize("cfmt", ["full", "bitmap"])
+def test_complex_accumulated_into_a_dense_C(gba, accum, cfmt):
+    n = 30
+    rng = np.random.default_rng(8)
+    A, B = _rand(n, n, 0.15, 9), _rand(n, n, 0.15, 10)
+    vals = rng.uniform(0.5, 2, (n, n)) + 1j * rng.uniform(-1, 1, (n, n))
+    C0 = Matrix.dense(vals, present=None if cfmt == "full" else rng.random((n, n)) < 0.5)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    gba.mxm(dC, None, accum, "PLUS_TIMES_FC64", dA, dB, None)
+    p, v = oracle.mxm_spec(C0, None, accum, "PLUS_TIMES_FC64", A, B)
+    assert_dense_same(dC.to_host(), p, v, exact=True, what=f"{accum}/{cfmt}")
+
+
+@pytest.mark.parametrize("t", [Type.FC32, Type.FC64])
+def test_complex_mxv_and_vxm(gba, t):
+    """w = A*u and w' = u'*A; vxm hands the multiplier its operands flipped (Source/GrB_vxm.c:63-72), which
+    MINUS and DIV show."""
+    n = 64
+    dt = np.complex64 if t == Type.FC32 else np.complex128
+    rng = np.random.default_rng(11)
+    A = _rand(n, n, 0.1, 12, t)
+    u = Matrix.full_vector((rng.uniform(0.5, 2, n) + 1j * rng.uniform(-1, 1, n)).astype(dt))
+    idx = np.sort(rng.choice(n, 20, replace=False))
+    us = Matrix.sparse_vector(n, idx, (rng.uniform(0.5, 2, 20) + 1j * rng.uniform(-1, 1, 20)).astype(dt))
+    w0 = Matrix.sparse_vector(n, [], np.zeros(0, dt))
+    dA = A.to_device()
+    for vec in (u, us):
+        for mult in ("TIMES", "MINUS", "DIV", "FIRST"):
+            sr = f"PLUS_{mult}_{NAME[t]}"
+            dw, dv = w0.to_device(), vec.to_device()
+            gba.mxv(dw, None, None, sr, dA, dv, None)
+            p, v = oracle.mxm_spec(w0, None, None, sr, A, vec, "")
+            assert_dense_same(dw.to_host(), p, v, exact=True, what=f"mxv {sr}")
+            dw = w0.to_device()
+            gba.vxm(dw, None, None, sr, dv, dA, None)
+            # w' = u'*A  <=>  w = A'*u with mult (x = u(k), y = A(k,j))
+            p, v = oracle.mxm_spec(w0, None, None, sr, A, vec, "T0", flipxy=True)
+            assert_dense_same(dw.to_host(), p, v, exact=True, what=f"vxm {sr}")
+
+
+def test_complex_operands_staged_from_the_host(gba):
+    n = 32
+    A, B = _rand(n, n, 0.2, 13), _rand(n, n, 0.2, 14)
+    C0 = Matrix.sparse_empty(n, n, Type.FC64)
+    dC = C0.to_device()
+    keep = []
+
+    class HostView:
+        def __init__(self, M):
+            self.view = M.view(keep)
+
+        def ref(self):
+            import ctypes
+            return ctypes.byref(self.view)
+
+    gba.mxm(dC, None, None, "PLUS_TIMES_FC64", HostView(A), HostView(B), None)
+    p, v = oracle.mxm_spec(C0, None, None, "PLUS_TIMES_FC64", A, B)
+    assert_dense_same(dC.to_host(), p, v, exact=True)
+
+
+def test_complex_infinities_follow_annex_g(gba):
+    """(inf + i nan) * (1 + i) is an infinity, not nan + i nan: the C99 operator the CPU library compiles
+    (Source/Shared/GB_complex.h:237-238) recovers it, and so does the device."""
+    one = lambda a: Matrix(1, 1, Type.FC64, 2, True, p=[0, 1], i=[0], x=np.array([a], np.complex128))
+    for x, y in ((complex(np.inf, np.nan), 1 + 1j), (complex(np.inf, 1), complex(0, np.inf)), (complex(1e308, 1e308), complex(1e308, 1e308))):
+        A, B = one(x), one(y)
+        C0 = Matrix.sparse_empty(1, 1, Type.FC64, by_row=False)
+        dC = C0.to_device()
+        gba.mxm(dC, None, None, "PLUS_TIMES_FC64", A.to_device(), B.to_device(), None)
+        p, v = oracle.mxm_spec(C0, None, None, "PLUS_TIMES_FC64", A, B)
+        got = dC.to_host().x[0]
+        assert p.all()
+        assert np.array_equal(np.array([got]).view(np.float64), v.reshape(-1).view(np.float64), equal_nan=True), (x, y, got, v)
+
+
+def test_complex_calls_that_are_declined(gba):
+    n = 16
+    A = _rand(n, n, 0.2, 15)
+    rng = np.random.default_rng(16)
+    R = Matrix.from_scipy(sp.random(n, n, density=0.2, random_state=rng, format="csr"), type=Type.FP64)
+    dA, dR = A.to_device(), R.to_device()
+    dC = Matrix.sparse_empty(n, n, Type.FC64).to_device()
+    with pytest.raises(GrbError) as e:                            # a real operand would have to be cast
+        gba.mxm(dC, None, None, "PLUS_TIMES_FC64", dA, dR, None)
+    assert e.value.info == Info.NOT_IMPLEMENTED
+    with pytest.raises(GrbError) as e:                            # GrB_MIN_FC64 does not exist
+        gba.mxm(dC, None, None, "MIN_TIMES_FC64", dA, dA, None)
+    assert e.value.info == Info.DOMAIN_MISMATCH
+    dC2 = A.to_device()                                            # accum into a sparse C that holds entries
+    with pytest.raises(GrbError) as e:
+        gba.mxm(dC2, None, "PLUS_FC64", "PLUS_TIMES_FC64", dA, dA, None)
+    assert e.value.info == Info.NOT_IMPLEMENTED

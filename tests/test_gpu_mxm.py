@@ -228,7 +228,7 @@ def test_errors_mirror_grb_info(gba):
     assert rep.typecast == 3
     with pytest.raises(GrbError) as e:
         gba.mxm(C, None, None, gba.gba_semiring(gba.Op.PLUS, gba.Op.TIMES, Type.FC64, Type.FC64, Type.FC64), A, A, "T1")
-    assert e.value.info == Info.NOT_IMPLEMENTED                  # complex types stay on the CPU library
+    assert e.value.info == Info.NOT_IMPLEMENTED                  # casts between real and complex stay on the CPU library
 
 
 def _operand(kind, n, A, rng, t):

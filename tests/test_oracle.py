@@ -212,3 +212,78 @@ def test_mxm_spec_typecasts_operands_and_result():
     Bi = np.array([[0, 1], [2, -1]])                # B cast to int32 truncates toward zero
     want = np.array([[10, 20], [30, 40]]) + np.array([[1, 2], [3, 4]]) @ Bi
     assert p.all() and v.dtype == np.float32 and np.array_equal(v, want.astype(np.float32))
+
+
+def _rand_complex(n, m, density, seed, t=Type.FC64, by_row=True, gaussian_integers=True):
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, m, density=density, random_state=rng, format="csr").astype(np.complex128)
+    k = len(S.data)
+    if gaussian_integers:
+        S.data = rng.integers(1, 5, k) + 1j * rng.integers(-4, 5, k)
+    else:
+        S.data = rng.uniform(0.5, 2.0, k) + 1j * rng.uniform(-2.0, 2.0, k)
+    return Matrix.from_scipy(S, type=t, by_row=by_row)
+
+
+@pytest.mark.parametrize("t", [Type.FC32, Type.FC64])
+def test_complex_semirings_against_numpy(t):
+    """The built-in complex semirings (Source/Factories/GB_AxB_factory.c:46-243 with GB_COMPLEX): Gaussian-integer
+    values make every sum and product exact, so numpy's complex matmul is the answer bit for bit."""
+    name = "FC32" if t == Type.FC32 else "FC64"
+    A, B = _rand_complex(14, 11, 0.3, 51, t), _rand_complex(11, 9, 0.3, 52, t)
+    C0 = Matrix.sparse_empty(14, 9, t)
+    a, b = A.to_scipy().toarray(), B.to_scipy().toarray()
+    ap, bp = (a != 0), (b != 0)
+    tp = (ap.astype(int) @ bp.astype(int)) > 0
+    p, v = oracle.mxm_spec(C0, None, None, f"PLUS_TIMES_{name}", A, B)
+    assert np.array_equal(p, tp) and np.array_equal(v[p], (a @ b)[tp])
+    p, v = oracle.mxm_spec(C0, None, None, f"PLUS_FIRST_{name}", A, B)
+    assert np.array_equal(v[p], (a @ bp.astype(a.dtype))[tp])
+    p, v = oracle.mxm_spec(C0, None, None, f"PLUS_SECOND_{name}", A, B)
+    assert np.array_equal(v[p], (ap.astype(a.dtype) @ b)[tp])
+    p, v = oracle.mxm_spec(C0, None, None, f"PLUS_PAIR_{name}", A, B)
+    assert np.array_equal(v[p], (ap.astype(int) @ bp.astype(int))[tp].astype(a.dtype))
+    p, v = oracle.mxm_spec(C0, None, None, f"PLUS_MINUS_{name}", A, B)
+    assert np.array_equal(v[p], (a @ bp.astype(a.dtype) - ap.astype(a.dtype) @ b)[tp])
+    # the saxpy3 method on the same operands (by column), against the definition
+    Ac, Bc = _rand_complex(14, 11, 0.3, 51, t, by_row=False), _rand_complex(11, 9, 0.3, 52, t, by_row=False)
+    T = oracle.saxpy3(None, False, False, Ac, Bc, f"PLUS_TIMES_{name}", wait=True)
+    assert np.array_equal(T.to_scipy().toarray(), a @ b)
+
+
+def test_complex_division_is_the_librarys_own():
+    """GB_FC64_div (Source/GB_math.h:301-340): real and imaginary divisors divide componentwise, the rest goes
+    through Smith's two cases; single complex divides in double and rounds (GB_FC32_div, :379-389)."""
+    one = lambda t, a: Matrix(1, 1, t, Sparsity.SPARSE, True, p=[0, 1], i=[0], x=np.array([a]))
+    def quot(t, x, y, sr="PLUS_DIV"):
+        name = "FC32" if t == Type.FC32 else "FC64"
+        return oracle.saxpy3(None, False, False, one(t, x), one(t, y), f"{sr}_{name}").x[0]
+    assert quot(Type.FC64, 6 + 8j, 2 + 0j) == 3 + 4j
+    assert quot(Type.FC64, 6 + 8j, 0 + 2j) == 4 - 3j
+    assert quot(Type.FC64, 1 + 0j, 0j).real == np.inf                    # x / (0,0) divides by the real part
+    # |yr| >= |yi|: r = yi/yr, d = yr + r*yi
+    x, y = 1.25 + 2.5j, 4 + 2j
+    r = y.imag / y.real; d = y.real + r * y.imag
+    assert quot(Type.FC64, x, y) == complex((x.real + x.imag * r) / d, (x.imag - x.real * r) / d)
+    # |yr| < |yi|: r = yr/yi, d = r*yr + yi
+    y = 1 + 3j
+    r = y.real / y.imag; d = r * y.real + y.imag
+    assert quot(Type.FC64, x, y) == complex((x.real * r + x.imag) / d, (x.imag * r - x.real) / d)
+    assert quot(Type.FC64, x, y, "PLUS_RDIV") == quot(Type.FC64, y, x)
+    got = quot(Type.FC32, np.complex64(x), np.complex64(y))
+    assert got == np.complex64(complex((x.real * r + x.imag) / d, (x.imag * r - x.real) / d))
+    assert got.dtype == np.complex64
+
+
+def test_complex_accum_and_mask_in_the_definition():
+    t = Type.FC64
+    A, B = _rand_complex(10, 10, 0.3, 61, t), _rand_complex(10, 10, 0.3, 62, t)
+    C0 = Matrix.dense((np.arange(100).reshape(10, 10) * (1 - 1j)).astype(np.complex128))
+    Mk = Matrix.from_scipy(_rand_sparse(10, 10, 0.5, 63))
+    a, b = A.to_scipy().toarray(), B.to_scipy().toarray()
+    tp = ((a != 0).astype(int) @ (b != 0).astype(int)) > 0
+    p, v = oracle.mxm_spec(C0, None, "PLUS_FC64", "PLUS_TIMES_FC64", A, B)
+    assert p.all() and np.array_equal(v, C0.x.reshape(10, 10) + a @ b)
+    p, v = oracle.mxm_spec(Matrix.sparse_empty(10, 10, t), Mk, None, "PLUS_TIMES_FC64", A, B, "S")
+    mp = Mk.to_scipy().toarray() != 0
+    assert np.array_equal(p, tp & mp) and np.array_equal(v[p], (a @ b)[p])
