@@ -10,7 +10,11 @@
  * -- replayed by oracle/gauss_replay.c; Demo/Output/wildtype_demo.out:142-330 --
  * saxpy3 and dot3 on a 192-byte user-defined type -- replayed by
  * oracle/wildtype_replay.c; tests/test_oracle.py compares both with fixtures
- * transcribed from those files).
+ * transcribed from those files), and against results of the reference library
+ * itself for its built-in semirings: entry counts, checksums, multiply counts,
+ * triangle counts and BFS frontier sizes it produced on RMAT inputs that
+ * graphblas_amd/gen.py rebuilds edge for edge
+ * (tests/golden/reference_run_checksums.json, tests/test_reference_runs.py).
  * The reference library itself cannot be built in this environment: its
  * sources need GB_config.h and GB_JITpackage.c, which only its cmake build
  * generates.
