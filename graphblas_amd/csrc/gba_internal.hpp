@@ -193,6 +193,9 @@ gba_info saxbit(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
 gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum, const gba_semiring *s,
                      const gba_matrix *A, bool A_tran, const gba_matrix *B, bool B_tran, bool flipxy,
                      bool C_replace, bool Mask_comp, bool Mask_struct, gba_report *report);
+// gba_meta.hip: the accum/mask write-back on INT64 matrices that hold positions instead of values
+gba_info writeback_positions(gba_matrix *Cpos, const gba_matrix *M, bool has_accum, bool C_replace, bool Mask_comp,
+                             bool Mask_struct, gba_matrix *Tpos);
 inline bool is_complex_type(int t) { return t == GBA_FC32 || t == GBA_FC64; }
 gba_info transpose(gba_matrix *AT, const gba_matrix *A);
 gba_info to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owned);   // bitmap/full -> sparse copy

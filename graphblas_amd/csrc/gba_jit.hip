@@ -17,7 +17,7 @@
 
 namespace gba {
 
-struct JitKernels { hipModule_t module = nullptr; hipFunction_t dot = nullptr, accum = nullptr; };
+struct JitKernels { hipModule_t module = nullptr; hipFunction_t dot = nullptr, accum = nullptr, merge = nullptr; };
 
 static std::mutex g_jit_mu;
 static std::map<std::string, JitKernels> g_jit_cache;
@@ -83,6 +83,17 @@ static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, co
         "    const int64_t pos = Ti [p] * stride_i + lo * stride_j ;\n"
         "    if (!Cb || Cb [pos]) " + ACC + " (&Cx [pos], &Cx [pos], &Tx [p]) ;\n"
         "    else { Cx [pos] = Tx [p] ; Cb [pos] = 1 ; }\n"
+        "}\n"
+        // values of Z = accum (C,T) from the positions the write-back left behind (writeback_positions)
+        "extern \"C\" __global__ void gba_udt_merge (int64_t n, const int64_t *Zx, const int8_t *Zb, const " + T + " *Cx,\n"
+        "    const " + T + " *Tx, " + T + " *out)\n"
+        "{\n"
+        "    const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x ;\n"
+        "    if (p >= n || (Zb && !Zb [p])) return ;\n"
+        "    const uint64_t v = (uint64_t) Zx [p], pc = v & 0xffffffffull, pt = v >> 32 ;\n"
+        "    if (pc && pt) " + ACC + " (&out [p], &Cx [pc - 1], &Tx [pt - 1]) ;\n"
+        "    else if (pt) out [p] = Tx [pt - 1] ;\n"
+        "    else if (pc) out [p] = Cx [pc - 1] ;\n"
         "}\n";
 
     std::lock_guard<std::mutex> lock(g_jit_mu);
@@ -112,6 +123,7 @@ static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, co
     GBA_HIP(hipModuleLoadData(&k.module, code.data()));
     GBA_HIP(hipModuleGetFunction(&k.dot, k.module, "gba_udt_dot"));
     GBA_HIP(hipModuleGetFunction(&k.accum, k.module, "gba_udt_accum"));
+    GBA_HIP(hipModuleGetFunction(&k.merge, k.module, "gba_udt_merge"));
     g_jit_cache[key] = k;
     *out = k;
     return GBA_SUCCESS;
@@ -134,6 +146,71 @@ static gba_info sparse_lists(const gba_matrix *X, bool tran, bool want_rows, gba
     GBA_OK(transpose(&Tm, &S));
     owned.push_back(Tm.p); owned.push_back(Tm.i); owned.push_back(Tm.x);
     *out = Tm;
+    return GBA_SUCCESS;
+}
+
+__global__ void __launch_bounds__(256) positions_kernel(int64_t *x, int64_t n, int shift) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) x[p] = (p + 1) << shift;
+}
+
+// C<M> = accum (C,T), any combination that the typed write-back takes (sparse or bitmap/full C with entries,
+// any mask, replace or not, with or without accum), for values of s bytes: the pattern work is done by
+// writeback_positions on INT64 stand-ins, the compiled merge kernel then fetches or combines the values.
+// T is sparse, in C's orientation, and is consumed.
+static gba_info udt_writeback(gba_matrix *C, const gba_matrix *M, bool has_accum, bool C_replace, bool Mask_comp,
+                              bool Mask_struct, gba_matrix *T, const JitKernels &jit, size_t esize) {
+    hipStream_t st = ctx().stream;
+    struct Guard { gba_matrix *T; gba_matrix Cpos{}, Tpos{}; void *out = nullptr;
+                   ~Guard() { gba_matrix_free_content(&Cpos); gba_matrix_free_content(&Tpos); gba_matrix_free_content(T); gba_free(out); } } g{T};
+    if (C->iso || C->nzombies || is_hyper(C)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "gba_mxm_udt: write-back into an iso-valued, hypersparse or zombie-holding C");
+    const bool dense = is_dense_fmt(C);
+    const int64_t nslots = C->vlen * C->vdim;
+    const int64_t cnz = dense ? nslots : C->nvals, tnz = T->nvals;
+    const int64_t most = ((int64_t)1 << 32) - 2;
+    if (cnz > most || tnz > most) GBA_FAIL(GBA_NOT_IMPLEMENTED, "gba_mxm_udt: write-back of more than 2^32 - 2 entries");
+    auto dup = [&](const void *src, size_t bytes, void **dst) -> gba_info {
+        *dst = gba_malloc(bytes ? bytes : 1);
+        if (!*dst) GBA_FAIL(GBA_OUT_OF_MEMORY, "gba_mxm_udt: write-back copy of %zu bytes", bytes);
+        if (src && bytes) GBA_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyDeviceToDevice, st));
+        return GBA_SUCCESS;
+    };
+    auto positions = [&](int64_t n, int shift, void **dst) -> gba_info {
+        *dst = gba_malloc((size_t)(n > 0 ? n : 1) * 8);
+        if (!*dst) GBA_FAIL(GBA_OUT_OF_MEMORY, "gba_mxm_udt: positions of %ld entries", (long)n);
+        if (n > 0) hipLaunchKernelGGL(positions_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, reinterpret_cast<int64_t *>(*dst), n, shift);
+        return GBA_SUCCESS;
+    };
+    gba_matrix &Cpos = g.Cpos, &Tpos = g.Tpos;
+    Cpos = *C; Cpos.type = GBA_INT64; Cpos.p = Cpos.i = Cpos.h = nullptr; Cpos.x = nullptr; Cpos.b = nullptr;
+    if (is_sparse(C)) {
+        GBA_OK(dup(C->p, (size_t)(C->nvec + 1) * 8, (void **)&Cpos.p));
+        GBA_OK(dup(C->i, (size_t)cnz * 8, (void **)&Cpos.i));
+    } else if (is_bitmap(C)) {
+        GBA_OK(dup(C->b, (size_t)nslots, (void **)&Cpos.b));
+    }
+    GBA_OK(positions(cnz, 0, &Cpos.x));
+    Tpos = *T; Tpos.type = GBA_INT64; Tpos.iso = false; Tpos.x = nullptr;
+    T->p = T->i = T->h = nullptr; T->b = nullptr;            // the pattern of T now belongs to Tpos; T keeps its values
+    GBA_OK(positions(tnz, 32, &Tpos.x));
+    const void *Tx = T->x, *Cx = C->x;
+    GBA_OK(writeback_positions(&Cpos, M, has_accum, C_replace, Mask_comp, Mask_struct, &Tpos));
+    const bool zdense = is_dense_fmt(&Cpos);
+    int64_t zn = zdense ? nslots : Cpos.nvals;
+    g.out = gba_malloc((size_t)(zn > 0 ? zn : 1) * esize);
+    if (!g.out) GBA_FAIL(GBA_OUT_OF_MEMORY, "gba_mxm_udt: values of the result");
+    if (zn > 0) {
+        const int8_t *Zb = is_bitmap(&Cpos) ? Cpos.b : nullptr;
+        void *args[] = {&zn, &Cpos.x, (void *)&Zb, (void *)&Cx, (void *)&Tx, &g.out};
+        const hipError_t e = hipModuleLaunchKernel(jit.merge, (unsigned)ceil_div(zn, 256), 1, 1, 256, 1, 1, 0, st, args, nullptr);
+        if (e != hipSuccess) GBA_FAIL(GBA_PANIC, "launch of the compiled merge kernel: %s", hipGetErrorString(e));
+    }
+    GBA_HIP(hipStreamSynchronize(st));
+    gba_matrix_free_content(C);                              // the old arrays were read above
+    gba_free(Cpos.x);
+    *C = Cpos;
+    C->x = g.out; C->type = GBA_UDT; C->mem = GBA_MEM_DEVICE;
+    g.out = nullptr; Cpos = gba_matrix{};                   // handed over
     return GBA_SUCCESS;
 }
 
@@ -247,8 +324,17 @@ gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, con
         gba_matrix_free_content(&T);
         rep.done_in_place = 1;
     } else {
-        gba_matrix_free_content(&T);
-        GBA_FAIL(GBA_NOT_IMPLEMENTED, "gba_mxm_udt: this combination of accum, mask and C format");
+        // the general case: C holds entries that the mask or the accumulator must keep or combine
+        if (!C->is_csc) {
+            gba_matrix Tr;
+            info = transpose(&Tr, &T);
+            gba_matrix_free_content(&T);
+            if (info != GBA_SUCCESS) return info;
+            T = Tr;
+        }
+        T.is_csc = C->is_csc;
+        info = udt_writeback(C, M, has_accum, C_replace, Mask_comp, Mask_struct, &T, jit, s->type_size);
+        if (info != GBA_SUCCESS) return info;
     }
     if (report) { rep.kernel_ms = timer.stop_ms(); *report = rep; }
     return info;

@@ -617,6 +617,32 @@ struct Exec {
     ~Exec() { for (void *p : owned) gba_free(p); }
 };
 
+// C<M> = accum (C,T) for values of any size (user-defined and complex types, gba_jit.hip): the write-back runs
+// on INT64 stand-ins whose values are positions -- Cpos(i,j) = 1 + the place of C(i,j) in C's values, Tpos(i,j) =
+// (1 + the place of T(i,j)) << 32 -- with PLUS as the accumulator, so that an entry of the result tells where
+// its value comes from: the low half alone = C's entry kept, the high half alone = T's entry, both = accum of
+// the two.  Cpos owns copies of C's pattern arrays (they may be replaced); M is in the caller's orientation.
+gba_info writeback_positions(gba_matrix *Cpos, const gba_matrix *M, bool has_accum, bool C_replace, bool Mask_comp,
+                             bool Mask_struct, gba_matrix *Tpos) {
+    Call k{};
+    k.C = Cpos; k.M = M; k.C_replace = C_replace; k.Mask_comp = Mask_comp; k.Mask_struct = Mask_struct;
+    k.has_accum = has_accum; k.accum = gba_binop{GBA_PLUS, GBA_INT64};
+    k.A_in = k.B_in = nullptr;
+    Exec ex;
+    gba_matrix Mturned;
+    const gba_matrix *Mwb = M;
+    if (M && M->is_csc != Cpos->is_csc) {
+        gba_matrix Mw = *M;
+        if (is_sparse(&Mw) && (Mw.jumbled || Mw.nzombies)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "jumbled mask in the other orientation");
+        GBA_OK(transposed(&Mw, &Mturned, ex.owned));
+        Mturned.is_csc = Cpos->is_csc;
+        Mwb = &Mturned;
+    }
+    if (is_dense_fmt(Cpos)) return writeback_dense(k, Mwb, Tpos);
+    if (is_sparse(Cpos) && is_sparse(Tpos)) return writeback_sparse(k, Mwb, Tpos);
+    GBA_FAIL(GBA_NOT_IMPLEMENTED, "C<M> = accum (C,T) with C of sparsity %d and T of sparsity %d", Cpos->sparsity, Tpos->sparsity);
+}
+
 // Format combinations no specialised kernel takes (dense A with sparse B, two dense operands under a
 // sparse result, two sparse operands in dot form, ...).  The CPU has a template instance for every
 // combination (Source/Template/GB_AxB_dot2_meta.c, GB_AxB_saxbit_template.c); here the operands are

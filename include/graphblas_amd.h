@@ -237,7 +237,7 @@ void     gba_matrix_free_content(gba_matrix *A);
  * Source/Factories/GB_AxB_factory.c:46-243 -- are taken when A, B, C and the
  * accumulator all have the semiring's type; they run on the road of
  * gba_mxm_udt (operators compiled by hipRTC, one dot product per entry) and
- * share its limits on accum / mask / C combinations.
+ * share its limits.
  * Returns GBA_NOT_IMPLEMENTED for valid calls outside the device path
  * (casts to or from complex, user-defined ops -- see gba_mxm_udt --, ...):
  * the caller keeps the CPU library for those, like the GB_cuda_*_branch test
@@ -264,8 +264,10 @@ typedef struct {
 /* C<M> = accum (C, A*B) over a user-defined semiring: GrB_mxm for matrices of type GBA_UDT
  * (Source/GB_mxm.c:24).  accum_name/accum_defn NULL = no accumulator.  C may be the same handle as A or
  * B (A = A*A), not a copy of it.  Taken: every format and orientation of A and B; M sparse (any
- * orientation) or bitmap/full held by column; C empty, replaced, or unmasked without accum (C = T), and
- * C bitmap/full with accum and no mask (in place).  Anything else: GBA_NOT_IMPLEMENTED. */
+ * orientation) or bitmap/full held by column; every combination of accum, mask, complement and replace on a
+ * sparse, bitmap or full C, with or without entries (at most 2^32 - 2 entries in C and in A*B when C holds
+ * entries that the mask or the accumulator keeps).  Declined with GBA_NOT_IMPLEMENTED: hypersparse operands,
+ * an iso-valued or zombie-holding C that holds entries. */
 gba_info gba_mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
                      const gba_user_semiring *semiring, const gba_matrix *A, const gba_matrix *B,
                      const gba_descriptor *desc, gba_report *report);

@@ -166,7 +166,62 @@ def test_complex_calls_that_are_declined(gba):
     with pytest.raises(GrbError) as e:                            # GrB_MIN_FC64 does not exist
         gba.mxm(dC, None, None, "MIN_TIMES_FC64", dA, dA, None)
     assert e.value.info == Info.DOMAIN_MISMATCH
-    dC2 = A.to_device()                                            # accum into a sparse C that holds entries
-    with pytest.raises(GrbError) as e:
-        gba.mxm(dC2, None, "PLUS_FC64", "PLUS_TIMES_FC64", dA, dA, None)
+    with pytest.raises(GrbError) as e:                            # the accumulator would have to be cast
+        gba.mxm(dC, None, "PLUS_FP64", "PLUS_TIMES_FC64", dA, dA, None)
     assert e.value.info == Info.NOT_IMPLEMENTED
+
+
+@pytest.mark.parametrize("desc", ["", "R", "S", "RS", "SC", "RSC", "C", "T0", "ST1"])
+@pytest.mark.parametrize("accum", [None, "PLUS_FC64", "SECOND_FC64", "MINUS_FC64"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_complex_into_a_sparse_C_that_holds_entries(gba, desc, accum, masked):
+    """C<M> = accum (C, A*B) with a sparse, non-empty C (Source/GB_accum_mask.c): every combination of accum /
+    mask / complement / replace; the values of a 16-byte type ride through the write-back as positions."""
+    if not masked and any(ch in desc for ch in "SC"):
+        pytest.skip("mask modifiers without a mask")
+    n = 45
+    A, B = _rand(n, n, 0.1, 21), _rand(n, n, 0.1, 22)
+    C0 = _rand(n, n, 0.2, 23, by_row=(len(desc) % 2 == 0))
+    M = _mask(n, n, 0.35, 24) if masked else None
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    dM = M.to_device() if masked else None
+    gba.mxm(dC, dM, accum, "PLUS_TIMES_FC64", dA, dB, desc)
+    p, v = oracle.mxm_spec(C0, M, accum, "PLUS_TIMES_FC64", A, B, desc)
+    got = dC.to_host()
+    assert got.is_csc == C0.is_csc and got.type == Type.FC64
+    assert_dense_same(got, p, v, exact=True, what=f"{desc}/{accum}/{masked}")
+
+
+@pytest.mark.parametrize("desc", ["", "S", "RSC", "R"])
+@pytest.mark.parametrize("accum", [None, "TIMES_FC32"])
+@pytest.mark.parametrize("cfmt", ["bitmap", "full"])
+def test_complex_masked_into_a_dense_C(gba, desc, accum, cfmt):
+    n = 24
+    t = Type.FC32
+    rng = np.random.default_rng(25)
+    A, B = _rand(n, n, 0.2, 26, t), _rand(n, n, 0.2, 27, t)
+    vals = (rng.uniform(0.5, 2, (n, n)) + 1j * rng.uniform(-1, 1, (n, n))).astype(np.complex64)
+    C0 = Matrix.dense(vals, present=None if cfmt == "full" else rng.random((n, n)) < 0.5, by_row=False)
+    M = _mask(n, n, 0.4, 28)
+    dA, dB, dC, dM = A.to_device(), B.to_device(), C0.to_device(), M.to_device()
+    gba.mxm(dC, dM, accum, "PLUS_TIMES_FC32", dA, dB, desc)
+    p, v = oracle.mxm_spec(C0, M, accum, "PLUS_TIMES_FC32", A, B, desc)
+    assert_dense_same(dC.to_host(), p, v, exact=True, what=f"{desc}/{accum}/{cfmt}")
+
+
+def test_complex_accumulating_over_iterations(gba):
+    """C += A*B three times: the result of one call (jumbled) is the C of the next."""
+    n = 60
+    rng = np.random.default_rng(29)
+    def gi(seed):
+        S = sp.random(n, n, density=0.06, random_state=np.random.default_rng(seed), format="csr").astype(np.complex128)
+        S.data = rng.integers(1, 4, len(S.data)) + 1j * rng.integers(-3, 4, len(S.data))
+        return Matrix.from_scipy(S, type=Type.FC64)
+    A, B, C0 = gi(30), gi(31), gi(32)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    S = C0.to_scipy().toarray()
+    P = A.to_scipy().toarray() @ B.to_scipy().toarray()
+    for _ in range(3):
+        gba.mxm(dC, None, "PLUS_FC64", "PLUS_TIMES_FC64", dA, dB, None)
+        S = S + P
+    assert np.array_equal(dC.to_host().to_scipy().toarray(), S)

@@ -190,3 +190,53 @@ def test_wildtype_demo_on_the_device(gba):
     _wild_check(dC.to_host(), want[3])
     for d in (dA, dB, dC, dM):
         d.free()
+
+
+@pytest.mark.parametrize("desc", ["", "R", "S", "RSC", "C"])
+@pytest.mark.parametrize("with_accum", [False, True])
+def test_gauss_into_a_sparse_C_that_holds_entries(gba, desc, with_accum):
+    """C<M> = accum (C, A*B) on the user-defined type with a sparse, non-empty C: the values ride through the
+    write-back as positions (Source/GB_accum_mask.c semantics).  Expected result: the same call on Gaussian
+    integers held as numpy complex numbers."""
+    import scipy.sparse as sp
+    n = 40
+    dt = g.register_udt(np.dtype([("real", "<i4"), ("imag", "<i4")]))
+    sr = g.user_semiring("gauss", GAUSS_DEFN, dt.itemsize, "addgauss", ADD_DEFN, "multgauss", MULT_DEFN)
+    rng = np.random.default_rng(7)
+
+    def rand(seed, density):
+        S = sp.random(n, n, density=density, random_state=np.random.default_rng(seed), format="csr").astype(np.complex128)
+        S.data = rng.integers(1, 5, len(S.data)) + 1j * rng.integers(-4, 5, len(S.data))
+        S.sort_indices()
+        x = np.zeros(len(S.data), dt)
+        x["real"], x["imag"] = S.data.real.astype(np.int32), S.data.imag.astype(np.int32)
+        return S, Matrix(n, n, Type.UDT, Sparsity.SPARSE, False, p=S.indptr, i=S.indices, x=x)
+
+    (Sa, A), (Sb, B), (Sc, C0) = rand(1, 0.1), rand(2, 0.1), rand(3, 0.2)
+    Sm = sp.random(n, n, density=0.4, random_state=np.random.default_rng(4), format="csr")
+    Sm.data = rng.integers(0, 2, len(Sm.data)).astype(np.float64)
+    M = Matrix.from_scipy(Sm, type=Type.INT8)
+    dA, dB, dC, dM = A.to_device(), B.to_device(), C0.to_device(), M.to_device()
+    g.mxm_udt(dC, dM, ("addgauss", ADD_DEFN) if with_accum else None, sr, dA, dB, desc)
+    r, c, v = dC.to_host().coo()
+    got = np.zeros((n, n), np.complex128); gp = np.zeros((n, n), bool)
+    got[r, c] = v["real"] + 1j * v["imag"]; gp[r, c] = True
+    # the definition, densely
+    a, b, cc = Sa.toarray(), Sb.toarray(), Sc.toarray()
+    tp = ((a != 0).astype(int) @ (b != 0).astype(int)) > 0
+    t = a @ b
+    cp = cc != 0
+    mp = (Sm.toarray() != 0) if "S" not in desc else np.zeros((n, n), bool)
+    if "S" in desc:                                  # structural: every stored entry counts, zeros included
+        mp[np.repeat(np.arange(n), np.diff(Sm.indptr)), Sm.indices] = True
+    if "C" in desc:
+        mp = ~mp
+    if with_accum:
+        zp, z = cp | tp, np.where(cp & tp, cc + t, np.where(cp, cc, t))
+    else:
+        zp, z = tp, t
+    keep_c = cp & ~mp & ("R" not in desc)
+    wp = (mp & zp) | keep_c
+    w = np.where(mp, z, cc)
+    assert np.array_equal(gp, wp), desc
+    assert np.array_equal(got[wp], w[wp]), desc
