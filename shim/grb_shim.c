@@ -6,8 +6,10 @@
  *      GxB_Vector_unpack_CSC/Bitmap/Full (Include/GraphBLAS.h:9869-10158; O(1): 9298-9303);
  *   2. gba_mxm / gba_mxv / gba_vxm run the multiply on the MI355X (include/graphblas_amd.h);
  *   3. everything is packed back (GxB_Matrix_pack_*, GxB_Vector_pack_*, 9342-9760).
- * A call the device path does not take (user-defined types, casts to or from complex, iso-valued operands,
- * an operator without a built-in code, GBA_NOT_IMPLEMENTED from the library) goes to the next definition of the same
+ * A semiring over one user-defined type goes to gba_mxm_udt with the strings the application gave to
+ * GxB_Type_new / GxB_BinaryOp_new (shim_run_udt).
+ * A call the device path does not take (casts to or from complex or user-defined types, an iso-valued C,
+ * an operator without a built-in code or definition, GBA_NOT_IMPLEMENTED from the library) goes to the next definition of the same
  * symbol, dlsym (RTLD_NEXT, ...): the CPU library, with its arguments untouched.
  *
  * Memory: the handles hold host arrays of the allocator given to GxB_init.  A, B and the mask are handed
@@ -55,9 +57,10 @@ static const struct { const char *name ; gba_opcode code ; } shim_ops [ ] = {
  * GxB codes, Include/GraphBLAS.h:4093-4094) */
 static bool shim_type (gba_type *t, int32_t code)
 {
+    if (code == GrB_UDT_CODE) { (*t) = GBA_UDT ; return (true) ; }          /* goes to gba_mxm_udt (shim_run_udt) */
     if (code == GxB_FC32_CODE) { (*t) = GBA_FC32 ; return (true) ; }
     if (code == GxB_FC64_CODE) { (*t) = GBA_FC64 ; return (true) ; }
-    if (code < GrB_BOOL_CODE || code > GrB_FP64_CODE) return (false) ;      /* user-defined */
+    if (code < GrB_BOOL_CODE || code > GrB_FP64_CODE) return (false) ;
     (*t) = (gba_type) code ;
     return (true) ;
 }
@@ -271,10 +274,13 @@ static GrB_Info shim_pack (shim_operand *o)
 
 /* --------------------------------------------------------------- the output -- */
 
+static size_t shim_udt_size = 0 ;       /* bytes per value of the GBA_UDT views while a user-defined call is running */
+
 static size_t shim_type_size (gba_type t)
 {
     switch (t)
     {
+        case GBA_UDT : return (shim_udt_size) ;
         case GBA_BOOL : case GBA_INT8 : case GBA_UINT8 : return (1) ;
         case GBA_INT16 : case GBA_UINT16 : return (2) ;
         case GBA_INT32 : case GBA_UINT32 : case GBA_FP32 : return (4) ;
@@ -380,20 +386,8 @@ static void shim_repack_inputs (shim_call *k)
     if (k->has_mask) shim_pack (&(k->m)) ;
 }
 
-/* true: handled on the device, *result is the GrB_Info to return.  false: nothing was changed, the caller
-   passes the call on to the CPU library. */
-static bool shim_run (GrB_Info *result, int which, shim_call *k, const GrB_BinaryOp accum,
-    const GrB_Semiring semiring, const GrB_Descriptor desc)
+static bool shim_device_ready (void)
 {
-    gba_semiring s ; gba_binop acc ; gba_descriptor d ;
-    if (semiring == NULL || !shim_semiring (&s, semiring)) return (false) ;
-    acc.op = GBA_NOP ; acc.type = s.ztype ;
-    if (accum != NULL)
-    {
-        gba_type ax, ay ;
-        if (!shim_binop (&(acc.op), &ax, &ay, &(acc.type), accum)) return (false) ;
-    }
-    shim_descriptor (&d, desc) ;
     static bool inited = false ;
     if (!inited)
     {
@@ -401,6 +395,31 @@ static bool shim_run (GrB_Info *result, int which, shim_call *k, const GrB_Binar
         if (gba_init (dev ? atoi (dev) : 0) != GBA_SUCCESS) return (false) ;
         inited = true ;
     }
+    return (true) ;
+}
+
+static bool shim_run_udt (GrB_Info *result, int which, shim_call *k, const GrB_BinaryOp accum,
+    const GrB_Semiring semiring, const GrB_Descriptor desc) ;
+
+/* true: handled on the device, *result is the GrB_Info to return.  false: nothing was changed, the caller
+   passes the call on to the CPU library. */
+static bool shim_run (GrB_Info *result, int which, shim_call *k, const GrB_BinaryOp accum,
+    const GrB_Semiring semiring, const GrB_Descriptor desc)
+{
+    gba_semiring s ; gba_binop acc ; gba_descriptor d ;
+    if (k->c.v.type == GBA_UDT) return (shim_run_udt (result, which, k, accum, semiring, desc)) ;
+    if (semiring == NULL || !shim_semiring (&s, semiring)) return (false) ;
+    if (k->a.v.type == GBA_UDT || k->b.v.type == GBA_UDT) return (false) ;     /* a built-in semiring on user-typed operands */
+    acc.op = GBA_NOP ; acc.type = s.ztype ;
+    if (accum != NULL)
+    {
+        gba_type ax, ay ;
+        if (!shim_binop (&(acc.op), &ax, &ay, &(acc.type), accum)) return (false) ;
+    }
+    shim_descriptor (&d, desc) ;
+    if (k->has_mask && k->m.v.type == GBA_UDT && !(d.mask == GBA_STRUCTURE || d.mask == GBA_COMP_STRUCTURE))
+        return (false) ;                                /* a user-typed mask read by value: the CPU library's error */
+    if (!shim_device_ready ()) return (false) ;
     gba_matrix cdev ;
     if (k->c.v.iso || !shim_upload (&cdev, &(k->c.v))) return (false) ;
     const gba_matrix *m = k->has_mask ? &(k->m.v) : NULL ;
@@ -412,6 +431,97 @@ static bool shim_run (GrB_Info *result, int which, shim_call *k, const GrB_Binar
     if (taken && info == GBA_SUCCESS) taken = shim_download (&(k->c), &cdev) ;
     gba_matrix_free_content (&cdev) ;
     if (taken) (*result) = (GrB_Info) info ;          /* the codes are the reference's (GrB_Info) */
+    return (taken) ;
+}
+
+/* ---------------------------------------------------------- user-defined types -- */
+
+/* The strings the application gave to GxB_Type_new and GxB_BinaryOp_new (Include/GraphBLAS.h:4056-4057,
+ * GxB_JIT_C_NAME / GxB_JIT_C_DEFINITION) are what the CPU library's own JIT compiles; gba_mxm_udt compiles the
+ * same strings for the device.  An object created without a definition cannot be compiled: the call stays on
+ * the CPU. */
+static char *shim_type_string (GrB_Type t, GrB_Field f)
+{
+    size_t n = 0 ;
+    if (GrB_Type_get_SIZE (t, &n, f) != GrB_SUCCESS || n <= 1) return (NULL) ;
+    char *str = malloc (n) ;
+    if (str != NULL && GrB_Type_get_String (t, str, f) != GrB_SUCCESS) { free (str) ; str = NULL ; }
+    return (str) ;
+}
+
+static char *shim_binop_string (GrB_BinaryOp op, GrB_Field f)
+{
+    size_t n = 0 ;
+    if (GrB_BinaryOp_get_SIZE (op, &n, f) != GrB_SUCCESS || n <= 1) return (NULL) ;
+    char *str = malloc (n) ;
+    if (str != NULL && GrB_BinaryOp_get_String (op, str, f) != GrB_SUCCESS) { free (str) ; str = NULL ; }
+    return (str) ;
+}
+
+static bool shim_operand_type (GrB_Type *t, const shim_operand *o)
+{
+    return ((o->A != NULL ? GxB_Matrix_type (t, o->A) : GxB_Vector_type (t, o->w)) == GrB_SUCCESS) ;
+}
+
+static bool shim_binop_is_over (GrB_BinaryOp op, int32_t code)
+{
+    int32_t xc, yc, zc ;
+    return (GrB_BinaryOp_get_INT32 (op, &zc, GrB_OUTP_TYPE_CODE) == GrB_SUCCESS && zc == code
+        && GrB_BinaryOp_get_INT32 (op, &xc, GrB_INP0_TYPE_CODE) == GrB_SUCCESS && xc == code
+        && GrB_BinaryOp_get_INT32 (op, &yc, GrB_INP1_TYPE_CODE) == GrB_SUCCESS && yc == code) ;
+}
+
+/* C<M> = accum (C, A*B) (which == 0) or w<m> = accum (w, A*u) (which == 2) over a semiring of one user-defined
+ * type.  Same contract as shim_run. */
+static bool shim_run_udt (GrB_Info *result, int which, shim_call *k, const GrB_BinaryOp accum,
+    const GrB_Semiring semiring, const GrB_Descriptor desc)
+{
+    if (which == 1 || semiring == NULL) return (false) ;           /* vxm flips the multiplier: left to the CPU */
+    if (k->c.v.type != GBA_UDT || k->a.v.type != GBA_UDT || k->b.v.type != GBA_UDT || k->c.v.iso) return (false) ;
+    GrB_Type tc, ta, tb ;
+    if (!shim_operand_type (&tc, &(k->c)) || !shim_operand_type (&ta, &(k->a)) || !shim_operand_type (&tb, &(k->b))
+        || ta != tc || tb != tc) return (false) ;
+    gba_descriptor d ;
+    shim_descriptor (&d, desc) ;
+    const bool structural = (d.mask == GBA_STRUCTURE || d.mask == GBA_COMP_STRUCTURE) ;
+    if (k->has_mask && k->m.v.type == GBA_UDT && !structural) return (false) ;
+    GrB_Monoid monoid ; GrB_BinaryOp add, mult ;
+    SHIM_OK (GxB_Semiring_add (&monoid, semiring)) ;
+    SHIM_OK (GxB_Monoid_operator (&add, monoid)) ;
+    SHIM_OK (GxB_Semiring_multiply (&mult, semiring)) ;
+    if (!shim_binop_is_over (add, GrB_UDT_CODE) || !shim_binop_is_over (mult, GrB_UDT_CODE)) return (false) ;
+    if (accum != NULL && !shim_binop_is_over (accum, GrB_UDT_CODE)) return (false) ;
+    size_t tsize = 0 ;
+    if (GxB_Type_size (&tsize, tc) != GrB_SUCCESS || tsize == 0) return (false) ;
+    char *str [8] = { shim_type_string (tc, GxB_JIT_C_NAME), shim_type_string (tc, GxB_JIT_C_DEFINITION),
+        shim_binop_string (add, GxB_JIT_C_NAME), shim_binop_string (add, GxB_JIT_C_DEFINITION),
+        shim_binop_string (mult, GxB_JIT_C_NAME), shim_binop_string (mult, GxB_JIT_C_DEFINITION),
+        accum ? shim_binop_string (accum, GxB_JIT_C_NAME) : NULL, accum ? shim_binop_string (accum, GxB_JIT_C_DEFINITION) : NULL } ;
+    bool taken = true ;
+    for (int q = 0 ; q < (accum ? 8 : 6) ; q++) taken = taken && (str [q] != NULL) ;
+    gba_matrix cdev, adev, bdev, mdev ;
+    memset (&cdev, 0, sizeof (cdev)) ; memset (&adev, 0, sizeof (adev)) ;
+    memset (&bdev, 0, sizeof (bdev)) ; memset (&mdev, 0, sizeof (mdev)) ;
+    if (taken && !shim_device_ready ()) taken = false ;
+    if (taken)
+    {
+        shim_udt_size = tsize ;
+        taken = shim_upload (&cdev, &(k->c.v)) && shim_upload (&adev, &(k->a.v)) && shim_upload (&bdev, &(k->b.v))
+            && (!k->has_mask || shim_upload (&mdev, &(k->m.v))) ;
+    }
+    if (taken)
+    {
+        gba_user_semiring us ;
+        us.type_name = str [0] ; us.type_defn = str [1] ; us.type_size = tsize ;
+        us.add_name = str [2] ; us.add_defn = str [3] ; us.mult_name = str [4] ; us.mult_defn = str [5] ;
+        const gba_info info = gba_mxm_udt (&cdev, k->has_mask ? &mdev : NULL, str [6], str [7], &us, &adev, &bdev, &d, NULL) ;
+        taken = (info != GBA_NOT_IMPLEMENTED && info != GBA_NO_VALUE) ;
+        if (taken && info == GBA_SUCCESS) taken = shim_download (&(k->c), &cdev) ;
+        if (taken) (*result) = (GrB_Info) info ;
+    }
+    gba_matrix_free_content (&cdev) ; gba_matrix_free_content (&adev) ;
+    gba_matrix_free_content (&bdev) ; gba_matrix_free_content (&mdev) ;
+    for (int q = 0 ; q < 8 ; q++) free (str [q]) ;
     return (taken) ;
 }
 
