@@ -322,9 +322,11 @@ def cpu_baseline(A, rf, target_madds):
     C = oracle.saxpy3(None, False, False, A, As, "PLUS_TIMES_FP64")      # internal operands: (A_I, B_I) = (A, sample rows)
     dt = time.perf_counter() - t
     return {"value": round(2.0 * madds / dt / 1e9, 4), "unit": "GFLOP/s", "cores": oracle.num_threads(), "kind": "port",
-            # what pins the port: the reference's printed results for its two user-type demos, replayed by the oracle
-            "validated_by": "oracle vs Demo/Output/gauss_demo.out and wildtype_demo.out (tests/test_oracle.py); "
-                            "the reference library itself does not build here",
+            # what pins the port: the reference's printed results for its two user-type demos, replayed by the oracle,
+            # and the recorded results of the reference library on RMAT inputs (PLUS_TIMES_FP64 saxpy3: this very kernel)
+            "validated_by": "oracle vs Demo/Output/gauss_demo.out and wildtype_demo.out (tests/test_oracle.py) and vs "
+                            "recorded runs of the reference library: nnz(C), sum(C), multiply count of C=A*A at RMAT-10/16 "
+                            "(tests/test_reference_runs.py); the reference library itself does not build here",
             "sample": f"rows 0,{stride},{2 * stride},... of A ({len(rows)} rows, {madds} multiply-adds, "
                       f"{100.0 * madds / total:.2f}% of the job, nnz(C sample)={C.nvals}) times the whole A; {dt:.1f} s",
             "seconds": round(dt, 2)}

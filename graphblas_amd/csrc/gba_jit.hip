@@ -132,9 +132,9 @@ static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, co
 // the operand as a sparse matrix whose vectors are the rows (want_rows) or the columns of op(X)
 static gba_info sparse_lists(const gba_matrix *X, bool tran, bool want_rows, gba_matrix *out, std::vector<void *> &owned) {
     gba_matrix S = *X;
-    if (is_hyper(X)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse operand");
     if (X->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "operand has zombies");
-    if (is_dense_fmt(X)) GBA_OK(to_sparse(X, &S, owned));
+    if (is_hyper(X)) GBA_OK(hyper_to_sparse(X, &S, owned));            // a pointer per vector; i and x are shared
+    else if (is_dense_fmt(X)) GBA_OK(to_sparse(X, &S, owned));
     // vectors of S are rows of X when X is held by row; op(X) = X' swaps rows and columns
     const bool vectors_are_rows = (!S.is_csc) != tran;
     if (vectors_are_rows == want_rows) {
@@ -253,13 +253,24 @@ gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, con
     GBA_OK(jit_build(s, accum_name, accum_defn, &jit));
 
     struct Owned { std::vector<void *> v; ~Owned() { for (void *p : v) gba_free(p); } } own;
+    // hypersparse mask and C: the sparse form of the same matrix (a pointer per vector); a C that came in
+    // hypersparse goes back hypersparse
+    gba_matrix Msp;
+    if (M && is_hyper(M)) { GBA_OK(hyper_to_sparse(M, &Msp, own.v)); M = &Msp; }
+    const bool C_was_hyper = is_hyper(C);
+    if (C_was_hyper) {
+        std::vector<void *> mine;
+        gba_matrix Csp;
+        GBA_OK(hyper_to_sparse(C, &Csp, mine));             // C owns its arrays: the new p replaces p and h
+        gba_free(C->p); gba_free(C->h);
+        *C = Csp;
+    }
     gba_matrix Arows, Acols, Bcols, Mcol;
     GBA_OK(sparse_lists(A, A_tran, true, &Arows, own.v));
     GBA_OK(sparse_lists(A, A_tran, false, &Acols, own.v));
     GBA_OK(sparse_lists(B, B_tran, false, &Bcols, own.v));
     const gba_matrix *Mc = nullptr;
     if (M) {
-        if (is_hyper(M)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse mask");
         Mcol = *M;
         if (!M->is_csc) {                                  // the pattern pass works by column
             if (is_sparse(M)) { GBA_OK(transpose(&Mcol, M)); own.v.push_back(Mcol.p); own.v.push_back(Mcol.i); own.v.push_back(Mcol.x); }
@@ -337,6 +348,7 @@ gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, con
         if (info != GBA_SUCCESS) return info;
     }
     if (report) { rep.kernel_ms = timer.stop_ms(); *report = rep; }
+    if (info == GBA_SUCCESS && C_was_hyper && is_sparse(C)) info = sparse_to_hyper(C);
     return info;
 }
 

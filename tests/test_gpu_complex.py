@@ -225,3 +225,21 @@ def test_complex_accumulating_over_iterations(gba):
         gba.mxm(dC, None, "PLUS_FC64", "PLUS_TIMES_FC64", dA, dB, None)
         S = S + P
     assert np.array_equal(dC.to_host().to_scipy().toarray(), S)
+
+
+@pytest.mark.parametrize("desc,accum", [("", None), ("RSC", None), ("S", "PLUS_FC64"), ("T0", "MINUS_FC64"), ("C", None)])
+def test_complex_hypersparse_operands(gba, desc, accum):
+    """Hypersparse A, B, mask and C are the same matrices: the result equals the sparse call's, and a C that
+    came in hypersparse goes back hypersparse."""
+    from graphblas_amd import Sparsity
+    n = 64
+    A, B = _rand(n, n, 0.02, 41), _rand(n, n, 0.02, 42, by_row=False)
+    C0, M = _rand(n, n, 0.02, 43), _mask(n, n, 0.05, 44)
+    Ah, Bh, Ch, Mh = A.to_hyper(), B.to_hyper(), C0.to_hyper(), M.to_hyper()
+    assert Ah.nvec < n and Bh.nvec < n and Ch.nvec < n
+    dC = Ch.to_device()
+    gba.mxm(dC, Mh.to_device(), accum, "PLUS_TIMES_FC64", Ah.to_device(), Bh.to_device(), desc)
+    p, v = oracle.mxm_spec(C0, M, accum, "PLUS_TIMES_FC64", A, B, desc)
+    got = dC.to_host()
+    assert got.sparsity == Sparsity.HYPERSPARSE
+    assert_dense_same(got, p, v, exact=True, what=f"{desc}/{accum}")
