@@ -461,8 +461,12 @@ gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
     const bool a_read = !(mult == GBA_SECOND || mult == GBA_PAIR), b_read = !(mult == GBA_FIRST || mult == GBA_PAIR);
     if (mult != GBA_PAIR && ((a_read && s->xtype != zt) || (b_read && s->ytype != zt)))
         GBA_FAIL(GBA_NOT_IMPLEMENTED, "complex monoid with a multiplier over types %d, %d", s->xtype, s->ytype);
-    if (C->type != zt || A->type != zt || B->type != zt)
-        GBA_FAIL(GBA_NOT_IMPLEMENTED, "complex semiring of type %d with C, A, B of types %d, %d, %d (typecast)", zt, C->type, A->type, B->type);
+    // A and B of another built-in type are cast to the semiring's (real part = the value, Source/GB_casting.h); a C
+    // of another type would need the product cast back, which is left to the CPU library
+    if (C->type != zt) GBA_FAIL(GBA_NOT_IMPLEMENTED, "complex semiring of type %d into a C of type %d (typecast)", zt, C->type);
+    for (const gba_matrix *X : {A, B})
+        if (X->type != zt && !is_real_type(X->type) && !is_complex_type(X->type))
+            GBA_FAIL(GBA_DOMAIN_MISMATCH, "operand of type %d under a complex semiring", X->type);
     if (C->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_NOT_IMPLEMENTED, "C must be a device view (mem == GBA_MEM_DEVICE)");
     if (M && !Mask_struct && !is_real_type(M->type)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "valued mask of type %d", M->type);
     std::string add_name, add_defn, mult_name, mult_defn, acc_name, acc_defn;
@@ -484,6 +488,10 @@ gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
     if (A->mem == GBA_MEM_HOST) GBA_OK(stage_to_device(A, &Av, own.v)); else Av = *A;
     if (B->mem == GBA_MEM_HOST) GBA_OK(stage_to_device(B, &Bv, own.v)); else Bv = *B;
     if (M) { if (M->mem == GBA_MEM_HOST) GBA_OK(stage_to_device(M, &Mv, own.v)); else Mv = *M; }
+    gba_matrix Ac, Bc;
+    if (Av.type != zt) { GBA_OK(cast_operand(&Av, zt, &Ac, own.v)); Av = Ac; }
+    if (Bv.type != zt) { GBA_OK(cast_operand(&Bv, zt, &Bc, own.v)); Bv = Bc; }
+    const int typecast = (A->type != zt ? 1 : 0) | (B->type != zt ? 2 : 0);
     Av.type = Bv.type = Cv.type = GBA_UDT;
     gba_descriptor d{};
     d.out = C_replace ? GBA_REPLACE : GBA_DEFAULT;
@@ -493,6 +501,7 @@ gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
                                   &us, &Av, &Bv, &d, report);
     Cv.type = zt;
     *C = Cv;                    // on failure mxm_udt leaves the view as it was
+    if (report && info == GBA_SUCCESS) report->typecast = typecast;
     return info;
 }
 

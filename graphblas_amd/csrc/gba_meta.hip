@@ -306,6 +306,27 @@ cast_kernel(int64_t n, const From *__restrict__ x, To *__restrict__ z) {
     for (; p < n; p += stride) z[p] = cast_value<To, From>(x[p]);
 }
 
+// to a complex type: the real part is the C cast of a real value, the imaginary part zero; complex to complex
+// converts both parts (Source/GB_casting.h: GB_CAST_FC32 / GB_CAST_FC64 by the C conversion rules)
+template <class R> struct cplx { R re, im; };
+template <class R, class From>
+__global__ void __launch_bounds__(256)
+cast_to_complex_kernel(int64_t n, const From *__restrict__ x, cplx<R> *__restrict__ z) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < n; p += stride) {
+        if constexpr (std::is_same<From, cplx<float>>::value || std::is_same<From, cplx<double>>::value) z[p] = cplx<R>{(R)x[p].re, (R)x[p].im};
+        else z[p] = cplx<R>{(R)x[p], (R)0};
+    }
+}
+
+template <class R, class F>
+static gba_info with_source_type(int code, F &&f) {
+    if (code == GBA_FC32) return f(cplx<float>());
+    if (code == GBA_FC64) return f(cplx<double>());
+    return with_type(code, f);
+}
+
 // X with its values in another built-in type: a new x array, the pattern arrays shared
 // (what GB_GETA / GB_cast_matrix do entry by entry on the CPU, Source/GB_cast_matrix.c)
 static gba_info cast_values(const gba_matrix *X, int to_type, gba_matrix *out, std::vector<void *> &owned) {
@@ -324,6 +345,18 @@ static gba_info cast_values(const gba_matrix *X, int to_type, gba_matrix *out, s
     const uint8_t *xsrc = reinterpret_cast<const uint8_t *>(X->x) + (size_t)p0 * esize_of(X->type);
     if (n > 0 && X->x) {
         int64_t blocks = ceil_div(n, 256); if (blocks > 8192) blocks = 8192;
+        if (is_complex_type(to_type)) {
+            auto launch = [&](auto r) -> gba_info {
+                using R = decltype(r);
+                return with_source_type<R>(X->type, [&](auto from) -> gba_info {
+                    using From = decltype(from);
+                    hipLaunchKernelGGL((cast_to_complex_kernel<R, From>), dim3((unsigned)blocks), dim3(256), 0, ctx().stream, n,
+                                       reinterpret_cast<const From *>(xsrc), reinterpret_cast<cplx<R> *>(z));
+                    return GBA_SUCCESS;
+                });
+            };
+            GBA_OK(to_type == GBA_FC32 ? launch(float()) : launch(double()));
+        } else
         GBA_OK(with_type(to_type, [&](auto to) -> gba_info {
             using To = decltype(to);
             return with_type(X->type, [&](auto from) -> gba_info {
@@ -339,6 +372,10 @@ static gba_info cast_values(const gba_matrix *X, int to_type, gba_matrix *out, s
     out->x = reinterpret_cast<uint8_t *>(z) - (size_t)p0 * esize_of(to_type);     // indexed by the same absolute offsets as X->x
     out->type = to_type;
     return GBA_SUCCESS;
+}
+
+gba_info cast_operand(const gba_matrix *X, int to_type, gba_matrix *out, std::vector<void *> &owned) {
+    return cast_values(X, to_type, out, owned);
 }
 
 static bool accum_op_ok(int op) {

@@ -732,6 +732,14 @@ static bool get_entry(const gba_matrix *A, int64_t row, int64_t col, const void 
  * comparison with zero (so NaN -> true). */
 void orc_cast(void *z, int ztype, const void *x, int xtype) {
     double d = 0; int64_t si = 0; uint64_t ui = 0; int kind;           /* 0 signed, 1 unsigned, 2 floating */
+    if (ztype == GBA_FC32 || ztype == GBA_FC64) {
+        /* to complex: the C conversion, real part = the value, imaginary part 0; complex to complex part by part */
+        if (xtype == GBA_FC32) { const fc32_t c = *(const fc32_t *)x; if (ztype == GBA_FC32) *(fc32_t *)z = c; else *(fc64_t *)z = CMPLX((double)crealf(c), (double)cimagf(c)); return; }
+        if (xtype == GBA_FC64) { const fc64_t c = *(const fc64_t *)x; if (ztype == GBA_FC64) *(fc64_t *)z = c; else *(fc32_t *)z = CMPLXF((float)creal(c), (float)cimag(c)); return; }
+        if (ztype == GBA_FC32) { float r; orc_cast(&r, GBA_FP32, x, xtype); *(fc32_t *)z = CMPLXF(r, 0); }
+        else { double r; orc_cast(&r, GBA_FP64, x, xtype); *(fc64_t *)z = CMPLX(r, 0); }
+        return;
+    }
     switch (xtype) {
         case GBA_BOOL:   ui = *(const uint8_t *)x != 0; kind = 1; break;
         case GBA_INT8:   si = *(const int8_t *)x;   kind = 0; break;

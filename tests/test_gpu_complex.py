@@ -160,8 +160,9 @@ def test_complex_calls_that_are_declined(gba):
     R = Matrix.from_scipy(sp.random(n, n, density=0.2, random_state=rng, format="csr"), type=Type.FP64)
     dA, dR = A.to_device(), R.to_device()
     dC = Matrix.sparse_empty(n, n, Type.FC64).to_device()
-    with pytest.raises(GrbError) as e:                            # a real operand would have to be cast
-        gba.mxm(dC, None, None, "PLUS_TIMES_FC64", dA, dR, None)
+    dCr = Matrix.sparse_empty(n, n, Type.FP64).to_device()
+    with pytest.raises(GrbError) as e:                            # the complex product would have to be cast to real
+        gba.mxm(dCr, None, None, "PLUS_TIMES_FC64", dA, dR, None)
     assert e.value.info == Info.NOT_IMPLEMENTED
     with pytest.raises(GrbError) as e:                            # GrB_MIN_FC64 does not exist
         gba.mxm(dC, None, None, "MIN_TIMES_FC64", dA, dA, None)
@@ -243,3 +244,38 @@ def test_complex_hypersparse_operands(gba, desc, accum):
     got = dC.to_host()
     assert got.sparsity == Sparsity.HYPERSPARSE
     assert_dense_same(got, p, v, exact=True, what=f"{desc}/{accum}")
+
+
+@pytest.mark.parametrize("ta,tb", [(Type.FP64, Type.FC64), (Type.FC64, Type.INT32), (Type.FC32, Type.FC64), (Type.FP32, Type.BOOL),
+                                   (Type.UINT8, Type.FC32)])
+@pytest.mark.parametrize("mult", ["TIMES", "FIRST", "SECOND", "DIV"])
+def test_operands_of_other_types_are_cast_to_complex(gba, ta, tb, mult):
+    """A and B of another built-in type under a complex semiring are cast to its type first (Source/GB_mxm.c:84-99,
+    Source/GB_casting.h): the real part takes the value, a complex value converts part by part."""
+    n = 36
+    zt = Type.FC32 if Type.FC32 in (ta, tb) and Type.FC64 not in (ta, tb) else Type.FC64
+
+    def make(t, seed, by_row):
+        rng = np.random.default_rng(seed)
+        S = sp.random(n, n, density=0.15, random_state=rng, format="csr").astype(np.complex128)
+        k = len(S.data)
+        if t in (Type.FC32, Type.FC64):
+            S.data = rng.uniform(0.5, 2.0, k) + 1j * rng.uniform(-2.0, 2.0, k)
+        elif t == Type.BOOL:
+            S.data = np.ones(k) + 0j
+        elif t in (Type.FP32, Type.FP64):
+            S.data = rng.uniform(0.5, 2.0, k) + 0j
+        else:
+            S.data = rng.integers(1, 9, k) + 0j
+        if t not in (Type.FC32, Type.FC64):
+            S = S.real
+        return Matrix.from_scipy(S, type=t, by_row=by_row)
+
+    A, B = make(ta, 51, True), make(tb, 52, False)
+    C0 = Matrix.sparse_empty(n, n, zt)
+    dC = C0.to_device()
+    sr = f"PLUS_{mult}_{NAME[zt]}"
+    rep = gba.mxm(dC, None, None, sr, A.to_device(), B.to_device(), None)
+    assert rep.typecast == (1 if ta != zt else 0) | (2 if tb != zt else 0)
+    p, v = oracle.mxm_spec(C0, None, None, sr, A, B)
+    assert_dense_same(dC.to_host(), p, v, exact=True, what=f"{sr} {ta} {tb}")
