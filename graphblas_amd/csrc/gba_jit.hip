@@ -273,8 +273,9 @@ gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, con
     if (M) {
         Mcol = *M;
         if (!M->is_csc) {                                  // the pattern pass works by column
-            if (is_sparse(M)) { GBA_OK(transpose(&Mcol, M)); own.v.push_back(Mcol.p); own.v.push_back(Mcol.i); own.v.push_back(Mcol.x); }
-            else GBA_FAIL(GBA_NOT_IMPLEMENTED, "gba_mxm_udt: bitmap/full mask held by row");
+            gba_matrix Ms = *M;
+            if (!is_sparse(M)) GBA_OK(to_sparse(M, &Ms, own.v));       // a bitmap/full mask held by row: its entries as lists first
+            GBA_OK(transpose(&Mcol, &Ms)); own.v.push_back(Mcol.p); own.v.push_back(Mcol.i); own.v.push_back(Mcol.x);
         }
         Mcol.is_csc = true;
         Mc = &Mcol;

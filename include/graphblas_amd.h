@@ -264,11 +264,11 @@ typedef struct {
 
 /* C<M> = accum (C, A*B) over a user-defined semiring: GrB_mxm for matrices of type GBA_UDT
  * (Source/GB_mxm.c:24).  accum_name/accum_defn NULL = no accumulator.  C may be the same handle as A or
- * B (A = A*A), not a copy of it.  Taken: every format and orientation of A and B; M sparse (any
- * orientation) or bitmap/full held by column; every combination of accum, mask, complement and replace on a
+ * B (A = A*A), not a copy of it.  Taken: every format and orientation of A, B and M (hypersparse
+ * included); every combination of accum, mask, complement and replace on a
  * sparse, bitmap or full C, with or without entries (at most 2^32 - 2 entries in C and in A*B when C holds
- * entries that the mask or the accumulator keeps).  Declined with GBA_NOT_IMPLEMENTED: hypersparse operands,
- * an iso-valued or zombie-holding C that holds entries. */
+ * entries that the mask or the accumulator keeps).  Declined with GBA_NOT_IMPLEMENTED: an iso-valued or
+ * zombie-holding C that holds entries. */
 gba_info gba_mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
                      const gba_user_semiring *semiring, const gba_matrix *A, const gba_matrix *B,
                      const gba_descriptor *desc, gba_report *report);

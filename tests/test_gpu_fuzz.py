@@ -185,3 +185,67 @@ def _check(gba, seed, sr, A, B, C0, M, accum, desc, vector):
         # a hypersparse C stays hypersparse: h lists exactly the non-empty vectors, in order
         assert got.sparsity == Sparsity.HYPERSPARSE, what
         assert np.all(np.diff(got.p) > 0) and np.all(np.diff(got.h) > 0), what
+
+
+COMPLEX_SEMIRINGS = [
+    ("PLUS_TIMES_FC64", Type.FC64, ["PLUS_FC64", "TIMES_FC64", "SECOND_FC64", "MINUS_FC64"]),
+    ("PLUS_TIMES_FC32", Type.FC32, ["PLUS_FC32", "FIRST_FC32"]),
+    ("TIMES_PLUS_FC64", Type.FC64, ["PLUS_FC64"]),
+    ("ANY_FIRST_FC32", Type.FC32, ["PLUS_FC32"]),
+    ("PLUS_PAIR_FC64", Type.FC64, ["PLUS_FC64", "RMINUS_FC64"]),
+    ("PLUS_RMINUS_FC32", Type.FC32, ["TIMES_FC32"]),
+    ("PLUS_SECOND_FC64", Type.FC64, ["PLUS_FC64"]),
+]
+
+
+def _random_complex_matrix(rng, nrows, ncols, t, fmt, by_row, density):
+    """Gaussian integers: sums and products stay exact in both precisions, whatever the order."""
+    dt = NP_TYPES[t]
+    vals = (rng.integers(1, 3, (nrows, ncols)) + 1j * rng.integers(-1, 2, (nrows, ncols))).astype(dt)
+    pres = rng.random((nrows, ncols)) < density
+    if fmt == "full":
+        return Matrix.dense(vals, by_row=by_row, type=t)
+    if fmt == "bitmap":
+        return Matrix.dense(vals, present=pres, by_row=by_row, type=t)
+    r, c = np.nonzero(pres)
+    if not by_row:
+        o = np.lexsort((r, c)); r, c = r[o], c[o]
+    vec, idx, nv = (r, c, nrows) if by_row else (c, r, ncols)
+    p = np.zeros(nv + 1, np.int64)
+    np.add.at(p, vec + 1, 1)
+    M = Matrix(ncols if by_row else nrows, nv, t, 2, not by_row, p=np.cumsum(p), i=idx, x=vals[r, c])
+    return M.to_hyper() if fmt == "hyper" else M
+
+
+def _complex_case(seed):
+    rng = np.random.default_rng(4000 + seed)
+    sr, t, accums = COMPLEX_SEMIRINGS[rng.integers(len(COMPLEX_SEMIRINGS))]
+    m, k, n = (int(x) for x in rng.integers(1, 24, 3))          # short sums: TIMES stays inside 2^24 in fp32
+    vector = rng.random() < 0.3
+    if vector:
+        n = 1
+    a_tran, b_tran = bool(rng.random() < 0.35), bool(rng.random() < 0.35) and not vector
+    fm = lambda: ["sparse", "sparse", "hyper", "bitmap", "full"][rng.integers(5)]
+    dens = 0.25 if sr.startswith("TIMES") else rng.choice([0.05, 0.3, 0.8])
+    A = _random_complex_matrix(rng, *((k, m) if a_tran else (m, k)), t, fm(), bool(rng.random() < 0.5), dens)
+    B = _random_complex_matrix(rng, *((n, k) if b_tran else (k, n)), t, fm() if not vector else ["sparse", "bitmap", "full"][rng.integers(3)],
+                               False if vector else bool(rng.random() < 0.5), dens)
+    c_fmt = ["empty", "sparse", "hyper", "bitmap", "full"][rng.integers(5)]
+    if vector and c_fmt == "hyper":
+        c_fmt = "sparse"
+    c_by_row = False if vector else bool(rng.random() < 0.5)
+    C0 = Matrix.sparse_empty(m, n, t, by_row=c_by_row) if c_fmt == "empty" else _random_complex_matrix(rng, m, n, t, c_fmt, c_by_row, 0.3)
+    M = None
+    if rng.random() < 0.6:
+        M = _random_matrix(rng, m, n, Type.INT8, ["sparse", "bitmap", "full"][rng.integers(3)],
+                           False if vector else bool(rng.random() < 0.5), 0.4)
+        M.x = (M.x % 2).astype(np.int8) if M.x is not None else M.x
+    accum = accums[rng.integers(len(accums))] if rng.random() < 0.5 else None
+    desc = ("R" if rng.random() < 0.3 else "") + (("S" if rng.random() < 0.5 else "") + ("C" if rng.random() < 0.4 else "") if M is not None else "") \
+        + ("T0" if a_tran else "") + ("T1" if b_tran else "")
+    return sr, A, B, C0, M, accum, desc, vector
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_call_with_complex_semirings(gba, seed):
+    _check(gba, seed, *_complex_case(seed))
