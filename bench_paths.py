@@ -6,6 +6,7 @@
   tricount  L = tril(A|A', -1), C<L,struct> = L*L' PLUS_PAIR_INT64 through gba_mxm (dot3), sum(C)
   bfs       level-synchronous BFS from the highest-degree vertex, one masked gba_vxm per level
   sssp      Bellman-Ford from the highest-degree vertex, one gba_vxm (MIN_PLUS_FP64, MIN accumulator) per iteration
+  complex   C = A*A with PLUS_TIMES_FC64 through gba_mxm (the hipRTC road of complex and user-defined types)
 
 Prints one JSON line per measurement: device time per call (HIP events on the library stream, from
 the call's report), algorithmic bytes per call and the HBM rate they give.
@@ -201,13 +202,40 @@ def sssp(args):
          reached=its[-1]["reached"], per_iteration=its)
 
 
+def complex_spgemm(args):
+    """C = A*A with PLUS_TIMES_FC64 through gba_mxm: the road of the user-defined types (pattern by the ANY_PAIR
+    kernels, then one compiled dot product per entry of C).  A is the RMAT pattern with complex values."""
+    import graphblas_amd as g
+    from graphblas_amd import gen, Type, Matrix, DeviceMatrix
+    A = gen.rmat(args.scale, 16, seed=42, type=Type.FP64)
+    rng = np.random.default_rng(1)
+    Ac = Matrix(A.vlen, A.vdim, Type.FC64, A.sparsity, A.is_csc, p=A.p, i=A.i, x=A.x + 1j * rng.random(len(A.x)))
+    n, nnz = A.nrows, A.nvals
+    dA = Ac.to_device()
+    res = []
+    for it in range(max(args.iters, 1)):
+        dC = DeviceMatrix.empty(n, n, Type.FC64)
+        g.sync(); t0 = time.perf_counter()
+        rep = g.mxm(dC, None, None, "PLUS_TIMES_FC64", dA, dA, None)
+        g.sync(); wall = (time.perf_counter() - t0) * 1e3
+        cnz = dC.view.nvals
+        dC.free()
+        res.append({"wall_ms": round(wall, 2), "kernel_ms": round(rep.kernel_ms, 2)})
+    dA.free()
+    best = min(r["wall_ms"] for r in res[1:] or res)
+    alg = (2 * nnz + cnz) * 24                        # int64 index + 16-byte value, A twice and C once
+    emit(case="C = A*A PLUS_TIMES_FC64 (hipRTC road)", workload=f"RMAT-{args.scale} ef=16 seed=42, complex values",
+         n=n, nnz_A=nnz, nnz_C=int(cnz), calls=res, best_wall_ms=best, algorithmic_bytes=alg,
+         achieved=round(alg / (best * 1e-3) / 1e9, 1), unit="GB/s", peak=HBM_PEAK_GBS)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["spmv", "tricount", "bfs", "sssp"])
+    ap.add_argument("what", choices=["spmv", "tricount", "bfs", "sssp", "complex"])
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--type", choices=["fp32", "fp64"], default="fp32", help="spmv value type")
     a = ap.parse_args()
     import graphblas_amd as g
     g.init(0)
-    {"spmv": spmv, "tricount": tricount, "bfs": bfs, "sssp": sssp}[a.what](a)
+    {"spmv": spmv, "tricount": tricount, "bfs": bfs, "sssp": sssp, "complex": complex_spgemm}[a.what](a)

@@ -59,7 +59,42 @@ static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, co
         "    const int64_t j = lo, i = Ti [p] ;\n"
         "    int64_t pa = Ap [i], pa1 = Ap [i+1], pb = Bp [j], pb1 = Bp [j+1] ;\n"
         "    " + T + " z ; int first = 1 ;\n"
-        "    while (pa < pa1 && pb < pb1)\n"
+        // a list more than eight times longer than the other is searched, not walked (the rule of
+        // Source/Template/GB_AxB_dot_cij.c:555-678); the terms still arrive in increasing k
+        "    const int64_t alen = pa1 - pa, blen = pb1 - pb ;\n"
+        "    if (alen > 8 * blen)\n"
+        "    {\n"
+        "        for ( ; pb < pb1 && pa < pa1 ; pb++)\n"
+        "        {\n"
+        "            const int64_t kb = Bi [pb] ;\n"
+        "            int64_t hi = pa1 ;\n"
+        "            while (pa < hi) { const int64_t mid = (pa + hi) >> 1 ; if (Ai [mid] < kb) pa = mid + 1 ; else hi = mid ; }\n"
+        "            if (pa < pa1 && Ai [pa] == kb)\n"
+        "            {\n"
+        "                " + T + " t ;\n"
+        "                " + MULT + " (&t, &Ax [A_iso ? 0 : pa], &Bx [B_iso ? 0 : pb]) ;\n"
+        "                if (first) { z = t ; first = 0 ; } else " + ADD + " (&z, &z, &t) ;\n"
+        "                pa++ ;\n"
+        "            }\n"
+        "        }\n"
+        "    }\n"
+        "    else if (blen > 8 * alen)\n"
+        "    {\n"
+        "        for ( ; pa < pa1 && pb < pb1 ; pa++)\n"
+        "        {\n"
+        "            const int64_t ka = Ai [pa] ;\n"
+        "            int64_t hi = pb1 ;\n"
+        "            while (pb < hi) { const int64_t mid = (pb + hi) >> 1 ; if (Bi [mid] < ka) pb = mid + 1 ; else hi = mid ; }\n"
+        "            if (pb < pb1 && Bi [pb] == ka)\n"
+        "            {\n"
+        "                " + T + " t ;\n"
+        "                " + MULT + " (&t, &Ax [A_iso ? 0 : pa], &Bx [B_iso ? 0 : pb]) ;\n"
+        "                if (first) { z = t ; first = 0 ; } else " + ADD + " (&z, &z, &t) ;\n"
+        "                pb++ ;\n"
+        "            }\n"
+        "        }\n"
+        "    }\n"
+        "    else while (pa < pa1 && pb < pb1)\n"
         "    {\n"
         "        const int64_t ka = Ai [pa], kb = Bi [pb] ;\n"
         "        if (ka < kb) pa++ ; else if (kb < ka) pb++ ;\n"
