@@ -67,8 +67,22 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     import torch
     dist = None
-    if world > 1:
+    # GBA_BENCH_FORCE_DIST=1: take the N > 1 code path (process group over RCCL, device-side partition, padded
+    # all-gather, reductions of the results) with however many ranks there are, even one -- the way to run that
+    # path on a one-GPU box.  The result of such a run with one rank is not a scaling measurement.
+    multi = world > 1 or bool(os.environ.get("GBA_BENCH_FORCE_DIST"))
+    if multi:
+        if "MASTER_ADDR" not in os.environ:            # a plain `python bench.py` with the switch set: one rank
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
         import torch.distributed as dist
+        # RCCL prints a version banner on the standard output when its communicator comes up; the one line this
+        # program owes its caller is the JSON record, so the banner is sent to the standard error instead
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if os.environ.get("GBA_BENCH_REHEARSE"):
             # rehearsal of the N > 1 code path on a box with one GPU: every rank on device 0, gloo
             # instead of RCCL (RCCL refuses two ranks on one device).  Not a measurement.
@@ -78,6 +92,11 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()                                  # the communicator exists from here on
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     import graphblas_amd as g
     from graphblas_amd import gen, Type, DeviceMatrix
     from graphblas_amd.dist import row_flops, split_by_flops, chunks_by_flops, RowBlockExchange
@@ -100,7 +119,7 @@ def main():
 
     # 1-D partition of rows over ranks, balanced by flops: the library's own split (the per-vector count saxpy3
     # bins by, gba_partition_by_flops), taken once on the pattern before the timed region
-    if world > 1:
+    if multi:
         Bi.copy_(torch.from_numpy(A.i))
         m0 = gba_matrix()
         m0.vlen, m0.vdim, m0.nvec, m0.nvals = n, n, n, nnzA
@@ -116,7 +135,7 @@ def main():
     e_lo, e_hi = int(A.p[my_lo]), int(A.p[my_hi])
     my_i = torch.from_numpy(A.i[e_lo:e_hi]).to(dev)
     my_x = torch.from_numpy(A.x[e_lo:e_hi]).to(dev)
-    xchg = RowBlockExchange(dist, torch, A.p, part, rank, dev, torch.int64, torch.float64)
+    xchg = RowBlockExchange(dist, torch, A.p, part, rank, dev, torch.int64, torch.float64, collective=multi)
 
     def exchange():
         """all-gather of the row blocks of A into the full right-hand operand (a copy on one GPU)."""
@@ -163,7 +182,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +194,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t1
-    if world > 1:
+    if multi:
         rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")      # gloo reduces host tensors
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -210,7 +229,7 @@ def main():
             "config": {"workload": f"RMAT-{args.scale} ef={args.edge_factor} seed=42 C=A*A via gba_mxm (CSR, int64 indices), "
                                    f"{len(my_chunks)} row chunks on rank 0, C released per chunk",
                        "n": n, "nnz_A": nnzA, "multiply_adds": total_madds, "nnz_C": cnz_all,
-                       "parallelism": f"rowblock{world}" + ("+allgatherB" if world > 1 else "")},
+                       "parallelism": f"rowblock{world}" + ("+allgatherB" if multi else "")},
             "hbm_GBps_compulsory": round(compulsory / sec_per_step / 1e9, 2),
             "phase_ms_per_step_rank0": [round(float(x) / args.steps, 3) for x in stats["phase_ms"]],
             "numeric_bin_vectors_rank0": [int(x) // max(args.steps, 1) for x in stats["bins"]],
@@ -232,7 +251,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on the one-GPU run only
             out["cpu_baseline"] = cpu_baseline(A, rf, args.cpu_flops)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -68,20 +68,22 @@ class RowBlockExchange:
     array on a flat buffer (blocks padded to the longest one, the collective wants equal shares),
     then one device copy per block into its place."""
 
-    def __init__(self, dist, torch, Ap, part, rank, device, idx_dtype, val_dtype):
+    def __init__(self, dist, torch, Ap, part, rank, device, idx_dtype, val_dtype, collective=None):
         self.dist, self.torch = dist, torch
         self.world = len(part) - 1
         self.rank = rank
+        # collective=True keeps the collective in the loop even for one rank (a process group must be up)
+        self.collective = (self.world > 1) if collective is None else bool(collective)
         self.offs = [int(Ap[part[r]]) for r in range(self.world)]
         self.counts = [int(Ap[part[r + 1]] - Ap[part[r]]) for r in range(self.world)]
-        self.pad = max(max(self.counts), 1) if self.world > 1 else 0
-        if self.world > 1:
+        self.pad = max(max(self.counts), 1) if self.collective else 0
+        if self.collective:
             self.si = torch.zeros(self.pad, dtype=idx_dtype, device=device)
             self.sx = torch.zeros(self.pad, dtype=val_dtype, device=device)
 
     def gather(self, my_i, my_x, out_i, out_x):
         """my_i/my_x: this rank's entries; out_i/out_x: full-length arrays to fill."""
-        if self.world == 1:
+        if not self.collective:
             out_i.copy_(my_i); out_x.copy_(my_x)
             return
         c = self.counts[self.rank]
