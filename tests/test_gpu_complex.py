@@ -279,3 +279,24 @@ def test_operands_of_other_types_are_cast_to_complex(gba, ta, tb, mult):
     assert rep.typecast == (1 if ta != zt else 0) | (2 if tb != zt else 0)
     p, v = oracle.mxm_spec(C0, None, None, sr, A, B)
     assert_dense_same(dC.to_host(), p, v, exact=True, what=f"{sr} {ta} {tb}")
+
+
+@pytest.mark.parametrize("accum", [None, "PLUS_FC64"])
+def test_complex_empty_operands_and_zero_dimensions(gba, accum):
+    """No entries in A, in B, in both; a 0-by-n and an n-by-0 product; C with entries is left as the definition says."""
+    n = 12
+    full = _rand(n, n, 0.3, 61)
+    empty = Matrix.sparse_empty(n, n, Type.FC64)
+    for A, B in ((empty, full), (full, empty), (empty, empty)):
+        for C0 in (Matrix.sparse_empty(n, n, Type.FC64), _rand(n, n, 0.2, 62)):
+            dC = C0.to_device()
+            gba.mxm(dC, None, accum, "PLUS_TIMES_FC64", A.to_device(), B.to_device(), None)
+            p, v = oracle.mxm_spec(C0, None, accum, "PLUS_TIMES_FC64", A, B)
+            assert_dense_same(dC.to_host(), p, v, exact=True, what=f"{A.nvals}/{B.nvals}/{C0.nvals}/{accum}")
+    for (m, k, q) in ((0, n, n), (n, 0, n), (n, n, 0)):
+        A = Matrix.sparse_empty(m, k, Type.FC64)
+        B = Matrix.sparse_empty(k, q, Type.FC64)
+        dC = Matrix.sparse_empty(m, q, Type.FC64).to_device()
+        gba.mxm(dC, None, accum, "PLUS_TIMES_FC64", A.to_device(), B.to_device(), None)
+        got = dC.to_host()
+        assert got.nvals == 0 and (got.nrows, got.ncols) == (m, q)
