@@ -198,6 +198,9 @@ gba_info writeback_positions(gba_matrix *Cpos, const gba_matrix *M, bool has_acc
                              bool Mask_struct, gba_matrix *Tpos);
 // gba_meta.hip: X with its values cast to another built-in type (real to real, anything to complex)
 gba_info cast_operand(const gba_matrix *X, int to_type, gba_matrix *out, std::vector<void *> &owned);
+// gba_meta.hip: C<M> = accum (C,T) for a product T of C's type (products computed in the other type family and cast)
+gba_info mxm_assign_cast(gba_matrix *C, const gba_matrix *M, const gba_binop *accum, bool C_replace, bool Mask_comp,
+                         bool Mask_struct, const gba_matrix *T, gba_report *report);
 inline bool is_complex_type(int t) { return t == GBA_FC32 || t == GBA_FC64; }
 gba_info transpose(gba_matrix *AT, const gba_matrix *A);
 gba_info to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owned);   // bitmap/full -> sparse copy

@@ -488,6 +488,7 @@ gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
     const int zt = s->ztype;
     const bool dbl = (zt == GBA_FC64);
     int mult = s->mult, add = s->add;
+    const bool flipxy_in = flipxy;
     mult = flip_binop(mult, &flipxy);
     if (flipxy) GBA_FAIL(GBA_NOT_IMPLEMENTED, "multiplier %d cannot be flipped", mult);
     if (!(add == GBA_PLUS || add == GBA_TIMES || add == GBA_ANY))
@@ -497,9 +498,29 @@ gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
     const bool a_read = !(mult == GBA_SECOND || mult == GBA_PAIR), b_read = !(mult == GBA_FIRST || mult == GBA_PAIR);
     if (mult != GBA_PAIR && ((a_read && s->xtype != zt) || (b_read && s->ytype != zt)))
         GBA_FAIL(GBA_NOT_IMPLEMENTED, "complex monoid with a multiplier over types %d, %d", s->xtype, s->ytype);
-    // A and B of another built-in type are cast to the semiring's (real part = the value, Source/GB_casting.h); a C
-    // of another type would need the product cast back, which is left to the CPU library
-    if (C->type != zt) GBA_FAIL(GBA_NOT_IMPLEMENTED, "complex semiring of type %d into a C of type %d (typecast)", zt, C->type);
+    // A and B of another built-in type are cast to the semiring's (real part = the value, Source/GB_casting.h).  A C
+    // of another built-in type: the product is computed into an empty matrix of the semiring's type, cast to C's
+    // type (the real part, Source/GB_casting.h:211-446) and assigned under the mask and the accumulator
+    if (C->type != zt) {
+        if (!is_real_type(C->type) && !is_complex_type(C->type)) GBA_FAIL(GBA_DOMAIN_MISMATCH, "C of type %d under a complex semiring", C->type);
+        if (C->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_NOT_IMPLEMENTED, "C must be a device view (mem == GBA_MEM_DEVICE)");
+        if (accum && accum->op != GBA_NOP && accum->type != C->type) GBA_FAIL(GBA_NOT_IMPLEMENTED, "accumulator of type %d on a C of type %d", accum->type, C->type);
+        const int64_t nvec = C->vdim;
+        gba_matrix Tt{};
+        Tt.vlen = C->vlen; Tt.vdim = Tt.nvec = nvec; Tt.type = zt; Tt.sparsity = GBA_SPARSE; Tt.mem = GBA_MEM_DEVICE; Tt.is_csc = C->is_csc;
+        Tt.p = reinterpret_cast<int64_t *>(gba_malloc((size_t)(nvec + 1) * 8));
+        if (!Tt.p) GBA_FAIL(GBA_OUT_OF_MEMORY, "pointers of the product");
+        struct Guard { gba_matrix *m; std::vector<void *> owned; ~Guard() { gba_matrix_free_content(m); for (void *p : owned) gba_free(p); } } g{&Tt, {}};
+        GBA_HIP(hipMemsetAsync(Tt.p, 0, (size_t)(nvec + 1) * 8, ctx().stream));
+        gba_report rep{};
+        GBA_OK(mxm_complex(&Tt, nullptr, nullptr, s, A, A_tran, B, B_tran, flipxy_in, false, false, false, &rep));
+        gba_matrix Tc;
+        GBA_OK(cast_operand(&Tt, C->type, &Tc, g.owned));
+        GBA_HIP(hipStreamSynchronize(ctx().stream));
+        const gba_info info = mxm_assign_cast(C, M, accum, C_replace, Mask_comp, Mask_struct, &Tc, nullptr);
+        if (report) { rep.typecast |= 4; *report = rep; }
+        return info;
+    }
     for (const gba_matrix *X : {A, B})
         if (X->type != zt && !is_real_type(X->type) && !is_complex_type(X->type))
             GBA_FAIL(GBA_DOMAIN_MISMATCH, "operand of type %d under a complex semiring", X->type);

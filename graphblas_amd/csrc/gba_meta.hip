@@ -306,9 +306,21 @@ cast_kernel(int64_t n, const From *__restrict__ x, To *__restrict__ z) {
     for (; p < n; p += stride) z[p] = cast_value<To, From>(x[p]);
 }
 
+template <class R> struct cplx { R re, im; };
+// complex to real (Source/GB_casting.h:211-446): bool is "either part non-zero", every other type casts the real part
+template <class To, class R>
+__global__ void __launch_bounds__(256)
+cast_from_complex_kernel(int64_t n, const cplx<R> *__restrict__ x, To *__restrict__ z) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < n; p += stride) {
+        if constexpr (std::is_same<To, bool>::value) z[p] = (x[p].re != 0 || x[p].im != 0);
+        else z[p] = cast_value<To, R>(x[p].re);
+    }
+}
+
 // to a complex type: the real part is the C cast of a real value, the imaginary part zero; complex to complex
 // converts both parts (Source/GB_casting.h: GB_CAST_FC32 / GB_CAST_FC64 by the C conversion rules)
-template <class R> struct cplx { R re, im; };
 template <class R, class From>
 __global__ void __launch_bounds__(256)
 cast_to_complex_kernel(int64_t n, const From *__restrict__ x, cplx<R> *__restrict__ z) {
@@ -356,6 +368,17 @@ static gba_info cast_values(const gba_matrix *X, int to_type, gba_matrix *out, s
                 });
             };
             GBA_OK(to_type == GBA_FC32 ? launch(float()) : launch(double()));
+        } else if (is_complex_type(X->type)) {
+            GBA_OK(with_type(to_type, [&](auto to) -> gba_info {
+                using To = decltype(to);
+                if (X->type == GBA_FC32)
+                    hipLaunchKernelGGL((cast_from_complex_kernel<To, float>), dim3((unsigned)blocks), dim3(256), 0, ctx().stream, n,
+                                       reinterpret_cast<const cplx<float> *>(xsrc), reinterpret_cast<To *>(z));
+                else
+                    hipLaunchKernelGGL((cast_from_complex_kernel<To, double>), dim3((unsigned)blocks), dim3(256), 0, ctx().stream, n,
+                                       reinterpret_cast<const cplx<double> *>(xsrc), reinterpret_cast<To *>(z));
+                return GBA_SUCCESS;
+            }));
         } else
         GBA_OK(with_type(to_type, [&](auto to) -> gba_info {
             using To = decltype(to);
@@ -1122,9 +1145,69 @@ static gba_info mxm_driver_sparse_C(Call k, gba_report *report, bool select_only
     GBA_FAIL(GBA_NOT_IMPLEMENTED, "C<M> = accum (C,T) with C of sparsity %d and T of sparsity %d", C->sparsity, T.sparsity);
 }
 
+static gba_info mxm_driver(Call k, gba_report *report, bool select_only);
+
+// C<M> = accum (C, T) for a product T that already has C's type: the write-back of GB_accum_mask, reached through
+// the front end itself as C<M> = accum (C, T*I) with the identity pattern I and ANY_FIRST, whose product is T
+// entry for entry.  Serves the products that had to be computed in one type family and cast to the other
+// (a complex product into a real C, a real product into a complex C).
+gba_info mxm_assign_cast(gba_matrix *C, const gba_matrix *M, const gba_binop *accum, bool C_replace, bool Mask_comp,
+                         bool Mask_struct, const gba_matrix *T, gba_report *report) {
+    hipStream_t st = ctx().stream;
+    const int64_t n = T->is_csc ? T->vdim : T->vlen;          // columns of T
+    DevBuf Ip, Ii, Ix;
+    GBA_OK(Ip.alloc((size_t)(n + 1) * 8)); GBA_OK(Ii.alloc((size_t)(n > 0 ? n : 1) * 8)); GBA_OK(Ix.alloc(16));
+    std::vector<int64_t> iota((size_t)n + 1);
+    for (int64_t q = 0; q <= n; q++) iota[(size_t)q] = q;
+    GBA_HIP(hipMemcpyAsync(Ip.p, iota.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    GBA_HIP(hipMemcpyAsync(Ii.p, iota.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    GBA_HIP(hipMemsetAsync(Ix.p, 0, 16, st));
+    GBA_HIP(hipStreamSynchronize(st));
+    gba_matrix I{};
+    I.vlen = I.vdim = I.nvec = I.nvals = n;
+    I.p = Ip.as<int64_t>(); I.i = Ii.as<int64_t>(); I.x = Ix.p;
+    I.type = C->type; I.sparsity = GBA_SPARSE; I.mem = GBA_MEM_DEVICE; I.is_csc = true; I.iso = true;
+    Call k{};
+    k.C = C; k.M = M; k.C_replace = C_replace; k.Mask_comp = Mask_comp; k.Mask_struct = Mask_struct;
+    k.has_accum = accum && accum->op != GBA_NOP;
+    if (k.has_accum) k.accum = *accum;
+    k.semiring = gba_semiring{GBA_ANY, GBA_FIRST, C->type, C->type, C->type};
+    k.A_in = T; k.B_in = &I;
+    k.AxB_method = GBA_AxB_SAXPY;
+    return mxm_driver(k, report, false);
+}
+
+// a real product into a complex C: T is computed in the semiring's type into an empty matrix, cast, and assigned
+static gba_info mxm_real_into_complex(Call k, gba_report *report) {
+    gba_matrix *C = k.C;
+    const int64_t nvec = C->vdim;
+    gba_matrix Tt{};
+    Tt.vlen = C->vlen; Tt.vdim = Tt.nvec = nvec; Tt.type = k.semiring.ztype; Tt.sparsity = GBA_SPARSE;
+    Tt.mem = GBA_MEM_DEVICE; Tt.is_csc = C->is_csc;
+    Tt.p = reinterpret_cast<int64_t *>(gba_malloc((size_t)(nvec + 1) * 8));
+    if (!Tt.p) GBA_FAIL(GBA_OUT_OF_MEMORY, "pointers of the product");
+    struct Guard { gba_matrix *m; std::vector<void *> owned; ~Guard() { gba_matrix_free_content(m); for (void *p : owned) gba_free(p); } } g{&Tt, {}};
+    GBA_HIP(hipMemsetAsync(Tt.p, 0, (size_t)(nvec + 1) * 8, ctx().stream));
+    Call kt = k;
+    kt.C = &Tt; kt.M = nullptr; kt.has_accum = false; kt.C_replace = false; kt.Mask_comp = false; kt.Mask_struct = false;
+    gba_report rep{};
+    GBA_OK(mxm_driver(kt, &rep, false));
+    if (is_hyper(&Tt)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "hypersparse product");
+    if (is_sparse(&Tt) && (Tt.jumbled || Tt.nzombies)) GBA_OK(matrix_wait(&Tt));      // the compiled dot kernels merge sorted lists
+    gba_matrix Tc;
+    GBA_OK(cast_values(&Tt, C->type, &Tc, g.owned));
+    GBA_HIP(hipStreamSynchronize(ctx().stream));
+    const gba_info info = mxm_assign_cast(C, k.M, k.has_accum ? &k.accum : nullptr, k.C_replace, k.Mask_comp, k.Mask_struct, &Tc, nullptr);
+    if (report) { rep.typecast |= 4; *report = rep; }
+    return info;
+}
+
 // A C that comes in hypersparse goes back hypersparse: the kernels work on its sparse form (a pointer per vector),
 // and the list of non-empty vectors is rebuilt from the result.
 static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
+    if (!select_only && k.C && is_complex_type(k.C->type) && is_real_type(k.semiring.ztype) && k.C->mem == GBA_MEM_DEVICE
+        && (!k.has_accum || k.accum.type == k.C->type))
+        return mxm_real_into_complex(k, report);
     if (is_complex_type(k.semiring.ztype) && !select_only)
         return mxm_complex(k.C, k.M, k.has_accum ? &k.accum : nullptr, &k.semiring, k.A_in, k.A_transpose, k.B_in,
                            k.B_transpose, k.flipxy, k.C_replace, k.Mask_comp, k.Mask_struct, report);

@@ -234,13 +234,14 @@ void     gba_matrix_free_content(gba_matrix *A);
  * report->mask_applied tells which happened.
  * The built-in complex semirings -- (PLUS, TIMES, ANY) x (FIRST, SECOND, PAIR,
  * PLUS, MINUS, RMINUS, TIMES, DIV, RDIV) over GBA_FC32 / GBA_FC64,
- * Source/Factories/GB_AxB_factory.c:46-243 -- are taken when C and the
- * accumulator have the semiring's type (A and B of any built-in type are cast
- * to it); they run on the road of
+ * Source/Factories/GB_AxB_factory.c:46-243 -- are taken with A, B and C of
+ * any built-in type (operands are cast to the semiring's type, the product to
+ * C's type: the real part, Source/GB_casting.h:211-446; a real product goes
+ * into a complex C the same way); the accumulator has C's type; they run on the road of
  * gba_mxm_udt (operators compiled by hipRTC, one dot product per entry) and
  * share its limits.
  * Returns GBA_NOT_IMPLEMENTED for valid calls outside the device path
- * (a complex product into a C of another type, user-defined ops -- see gba_mxm_udt --, ...):
+ * (user-defined ops -- see gba_mxm_udt --, an accumulator of another type than C, ...):
  * the caller keeps the CPU library for those, like the GB_cuda_*_branch test
  * in Source/GB_AxB_dot.c:189-197. */
 gba_info gba_mxm(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,

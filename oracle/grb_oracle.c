@@ -740,6 +740,15 @@ void orc_cast(void *z, int ztype, const void *x, int xtype) {
         else { double r; orc_cast(&r, GBA_FP64, x, xtype); *(fc64_t *)z = CMPLX(r, 0); }
         return;
     }
+    if (xtype == GBA_FC32 || xtype == GBA_FC64) {
+        /* from complex (Source/GB_casting.h:211-446): bool is "either part non-zero", the rest casts the real part */
+        const double re = (xtype == GBA_FC32) ? (double)crealf(*(const fc32_t *)x) : creal(*(const fc64_t *)x);
+        const double im = (xtype == GBA_FC32) ? (double)cimagf(*(const fc32_t *)x) : cimag(*(const fc64_t *)x);
+        if (ztype == GBA_BOOL) { *(uint8_t *)z = (re != 0 || im != 0); return; }
+        if (xtype == GBA_FC32) { const float r = crealf(*(const fc32_t *)x); orc_cast(z, ztype, &r, GBA_FP32); }
+        else orc_cast(z, ztype, &re, GBA_FP64);
+        return;
+    }
     switch (xtype) {
         case GBA_BOOL:   ui = *(const uint8_t *)x != 0; kind = 1; break;
         case GBA_INT8:   si = *(const int8_t *)x;   kind = 0; break;

@@ -8,7 +8,7 @@
  *   3. everything is packed back (GxB_Matrix_pack_*, GxB_Vector_pack_*, 9342-9760).
  * A semiring over one user-defined type goes to gba_mxm_udt with the strings the application gave to
  * GxB_Type_new / GxB_BinaryOp_new (shim_run_udt).
- * A call the device path does not take (casts to or from complex or user-defined types, an iso-valued C,
+ * A call the device path does not take (casts to or from user-defined types, an iso-valued C,
  * an operator without a built-in code or definition, GBA_NOT_IMPLEMENTED from the library) goes to the next definition of the same
  * symbol, dlsym (RTLD_NEXT, ...): the CPU library, with its arguments untouched.
  *

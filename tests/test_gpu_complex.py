@@ -160,10 +160,6 @@ def test_complex_calls_that_are_declined(gba):
     R = Matrix.from_scipy(sp.random(n, n, density=0.2, random_state=rng, format="csr"), type=Type.FP64)
     dA, dR = A.to_device(), R.to_device()
     dC = Matrix.sparse_empty(n, n, Type.FC64).to_device()
-    dCr = Matrix.sparse_empty(n, n, Type.FP64).to_device()
-    with pytest.raises(GrbError) as e:                            # the complex product would have to be cast to real
-        gba.mxm(dCr, None, None, "PLUS_TIMES_FC64", dA, dR, None)
-    assert e.value.info == Info.NOT_IMPLEMENTED
     with pytest.raises(GrbError) as e:                            # GrB_MIN_FC64 does not exist
         gba.mxm(dC, None, None, "MIN_TIMES_FC64", dA, dA, None)
     assert e.value.info == Info.DOMAIN_MISMATCH
@@ -300,3 +296,53 @@ def test_complex_empty_operands_and_zero_dimensions(gba, accum):
         gba.mxm(dC, None, accum, "PLUS_TIMES_FC64", A.to_device(), B.to_device(), None)
         got = dC.to_host()
         assert got.nvals == 0 and (got.nrows, got.ncols) == (m, q)
+
+
+def _typed(n, t, seed, density=0.2, by_row=True):
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, n, density=density, random_state=rng, format="csr").astype(np.complex128)
+    k = len(S.data)
+    if t in (Type.FC32, Type.FC64):
+        S.data = rng.integers(-3, 4, k) + 0.5 + 1j * rng.integers(-3, 4, k)
+    else:
+        S.data = rng.integers(1, 6, k) + 0j
+        S = S.real
+    return Matrix.from_scipy(S, type=t, by_row=by_row)
+
+
+@pytest.mark.parametrize("tc", [Type.FP64, Type.FP32, Type.INT32, Type.UINT8, Type.BOOL, Type.FC32])
+@pytest.mark.parametrize("accum,desc,masked", [(None, "", False), ("PLUS", "", False), (None, "S", True), ("SECOND", "RSC", True), ("PLUS", "T0", True)])
+def test_complex_product_into_a_C_of_another_type(gba, tc, accum, desc, masked):
+    """C of another built-in type under a complex semiring: T is cast to C's type before the accumulator and the mask
+    see it (Source/GB_mxm.c:84-99, Source/GB_casting.h:211-446: the real part; bool = either part non-zero)."""
+    n = 30
+    A, B = _typed(n, Type.FC64, 71), _typed(n, Type.FC64, 72, by_row=False)
+    C0 = _typed(n, tc, 73, density=0.15)
+    M = _mask(n, n, 0.4, 74) if masked else None
+    tname = {v: k for k, v in vars(Type).items() if isinstance(v, int)}[tc]
+    if tc == Type.BOOL and accum is not None:
+        accum = {"PLUS": "LOR", "SECOND": "SECOND"}[accum]
+    acc = None if accum is None else f"{accum}_{tname}"
+    dC = C0.to_device()
+    rep = gba.mxm(dC, M.to_device() if masked else None, acc, "PLUS_TIMES_FC64", A.to_device(), B.to_device(), desc)
+    assert rep.typecast & 4
+    p, v = oracle.mxm_spec(C0, M, acc, "PLUS_TIMES_FC64", A, B, desc)
+    got = dC.to_host()
+    assert got.type == tc
+    assert_dense_same(got, p, v, exact=True, what=f"{tname}/{acc}/{desc}")
+
+
+@pytest.mark.parametrize("sr,t", [("PLUS_TIMES_FP64", Type.FP64), ("MIN_PLUS_INT32", Type.INT32), ("LOR_LAND_BOOL", Type.BOOL)])
+@pytest.mark.parametrize("accum,desc,masked", [(None, "", False), ("PLUS_FC64", "", False), (None, "S", True), ("MINUS_FC64", "RC", True)])
+def test_real_product_into_a_complex_C(gba, sr, t, accum, desc, masked):
+    n = 30
+    A, B = _typed(n, t, 81), _typed(n, t, 82, by_row=False)
+    C0 = _typed(n, Type.FC64, 83, density=0.15)
+    M = _mask(n, n, 0.4, 84) if masked else None
+    dC = C0.to_device()
+    rep = gba.mxm(dC, M.to_device() if masked else None, accum, sr, A.to_device(), B.to_device(), desc)
+    assert rep.typecast & 4
+    p, v = oracle.mxm_spec(C0, M, accum, sr, A, B, desc)
+    got = dC.to_host()
+    assert got.type == Type.FC64
+    assert_dense_same(got, p, v, exact=True, what=f"{sr}/{accum}/{desc}")

@@ -226,9 +226,11 @@ def test_errors_mirror_grb_info(gba):
     B = _rand(10, 10, 0.3, 10, t=Type.INT32).to_device()
     rep = gba.mxm(C, None, None, "PLUS_TIMES_FP64", B, B, None)  # int32 operands are cast to the multiplier's fp64
     assert rep.typecast == 3
+    rep = gba.mxm(C, None, None, gba.gba_semiring(gba.Op.PLUS, gba.Op.TIMES, Type.FC64, Type.FC64, Type.FC64), A, A, "T1")
+    assert rep.typecast == 7                                     # real operands under a complex semiring into a real C
     with pytest.raises(GrbError) as e:
-        gba.mxm(C, None, None, gba.gba_semiring(gba.Op.PLUS, gba.Op.TIMES, Type.FC64, Type.FC64, Type.FC64), A, A, "T1")
-    assert e.value.info == Info.NOT_IMPLEMENTED                  # casts between real and complex stay on the CPU library
+        gba.mxm(C, None, None, gba.gba_semiring(gba.Op.PLUS, gba.Op.USER, Type.FP64, Type.FP64, Type.FP64), A, A, "T1")
+    assert e.value.info == Info.NOT_IMPLEMENTED                  # an operator without a built-in code stays on the CPU library
 
 
 def _operand(kind, n, A, rng, t):
