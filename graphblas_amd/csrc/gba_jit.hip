@@ -249,6 +249,10 @@ static gba_info udt_writeback(gba_matrix *C, const gba_matrix *M, bool has_accum
     return GBA_SUCCESS;
 }
 
+// set while a caller needs the product with sorted vectors (it goes on as the operand of another compiled dot
+// kernel): the pattern is sorted before the values are computed, so only indices move
+static bool g_udt_sorted_pattern = false;
+
 static gba_matrix pattern_view(const gba_matrix &S) {
     gba_matrix v = S;
     v.type = GBA_BOOL; v.iso = true;        // ANY_PAIR reads no values
@@ -323,7 +327,7 @@ gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, con
     gba_matrix Ap_ = pattern_view(Acols), Bp_ = pattern_view(Bcols), T{};
     Ap_.is_csc = Bp_.is_csc = true;
     bool applied = false;
-    GBA_OK(saxpy3(&T, Mc, Mask_comp, Mask_struct, &Ap_, &Bp_, c, 0, 0, &applied, nullptr));
+    GBA_OK(saxpy3(&T, Mc, Mask_comp, Mask_struct, &Ap_, &Bp_, c, 0, g_udt_sorted_pattern ? 1 : 0, &applied, nullptr));
     const int64_t tnz = T.nvals;
     gba_free(T.x); T.x = nullptr;                          // the boolean values are not wanted
     void *Tx = gba_malloc((size_t)(tnz > 0 ? tnz : 1) * s->type_size);
@@ -513,7 +517,10 @@ gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
         struct Guard { gba_matrix *m; std::vector<void *> owned; ~Guard() { gba_matrix_free_content(m); for (void *p : owned) gba_free(p); } } g{&Tt, {}};
         GBA_HIP(hipMemsetAsync(Tt.p, 0, (size_t)(nvec + 1) * 8, ctx().stream));
         gba_report rep{};
-        GBA_OK(mxm_complex(&Tt, nullptr, nullptr, s, A, A_tran, B, B_tran, flipxy_in, false, false, false, &rep));
+        {
+            struct Sorted { bool old; Sorted() : old(g_udt_sorted_pattern) { g_udt_sorted_pattern = true; } ~Sorted() { g_udt_sorted_pattern = old; } } sorted;
+            GBA_OK(mxm_complex(&Tt, nullptr, nullptr, s, A, A_tran, B, B_tran, flipxy_in, false, false, false, &rep));
+        }
         gba_matrix Tc;
         GBA_OK(cast_operand(&Tt, C->type, &Tc, g.owned));
         GBA_HIP(hipStreamSynchronize(ctx().stream));

@@ -873,10 +873,11 @@ static gba_info mxm_driver_sparse_C(Call k, gba_report *report, bool select_only
         const bool y_read = !positional && mult != GBA_FIRST && mult != GBA_PAIR;
         const bool a_read = k.flipxy ? y_read : x_read, b_read = k.flipxy ? x_read : y_read;
         const int a_want = k.flipxy ? second_type : first_type, b_want = k.flipxy ? first_type : second_type;
-        if (a_read && A_in->type != a_want && is_real_type(A_in->type) && is_real_type(a_want) && !select_only) {
+        auto builtin = [](int t) { return is_real_type(t) || is_complex_type(t); };     // a complex operand gives its real part
+        if (a_read && A_in->type != a_want && builtin(A_in->type) && is_real_type(a_want) && !select_only) {
             GBA_OK(cast_values(A_in, a_want, &Acast, ex.owned)); k.A_in = A_in = &Acast; ex.rep.typecast |= 1;
         }
-        if (b_read && B_in->type != b_want && is_real_type(B_in->type) && is_real_type(b_want) && !select_only) {
+        if (b_read && B_in->type != b_want && builtin(B_in->type) && is_real_type(b_want) && !select_only) {
             GBA_OK(cast_values(B_in, b_want, &Bcast, ex.owned)); k.B_in = B_in = &Bcast; ex.rep.typecast |= 2;
         }
     }

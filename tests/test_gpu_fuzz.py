@@ -249,3 +249,45 @@ def _complex_case(seed):
 @pytest.mark.parametrize("seed", range(120))
 def test_random_call_with_complex_semirings(gba, seed):
     _check(gba, seed, *_complex_case(seed))
+
+
+MIXED_TYPES = [Type.BOOL, Type.INT8, Type.UINT16, Type.INT32, Type.INT64, Type.FP32, Type.FP64, Type.FC32, Type.FC64]
+
+
+def _mixed_matrix(rng, nrows, ncols, t, fmt, by_row, density):
+    if t in (Type.FC32, Type.FC64):
+        return _random_complex_matrix(rng, nrows, ncols, t, fmt, by_row, density)
+    return _random_matrix(rng, nrows, ncols, t, fmt, by_row, density)
+
+
+def _mixed_case(seed):
+    """A, B and C of unrelated built-in types, real or complex, under a real or a complex semiring."""
+    rng = np.random.default_rng(6000 + seed)
+    pool = COMPLEX_SEMIRINGS[:2] + COMPLEX_SEMIRINGS[4:] + SEMIRINGS[:2] + SEMIRINGS[4:6]
+    sr, t, _ = pool[rng.integers(len(pool))]
+    ta, tb, tc = (MIXED_TYPES[rng.integers(len(MIXED_TYPES))] for _ in range(3))
+    if not any(x in (Type.FC32, Type.FC64) for x in (t, tc)):
+        tc = Type.FC64                               # every case crosses the boundary somewhere
+    m, k, n = (int(x) for x in rng.integers(1, 20, 3))
+    fm = lambda: ["sparse", "sparse", "hyper", "bitmap", "full"][rng.integers(5)]
+    a_tran, b_tran = bool(rng.random() < 0.3), bool(rng.random() < 0.3)
+    A = _mixed_matrix(rng, *((k, m) if a_tran else (m, k)), ta, fm(), bool(rng.random() < 0.5), 0.3)
+    B = _mixed_matrix(rng, *((n, k) if b_tran else (k, n)), tb, fm(), bool(rng.random() < 0.5), 0.3)
+    c_by_row = bool(rng.random() < 0.5)
+    c_fmt = ["empty", "sparse", "bitmap", "full"][rng.integers(4)]
+    C0 = Matrix.sparse_empty(m, n, tc, by_row=c_by_row) if c_fmt == "empty" else _mixed_matrix(rng, m, n, tc, c_fmt, c_by_row, 0.3)
+    M = None
+    if rng.random() < 0.5:
+        M = _random_matrix(rng, m, n, Type.INT8, ["sparse", "bitmap", "full"][rng.integers(3)], bool(rng.random() < 0.5), 0.4)
+        M.x = (M.x % 2).astype(np.int8)
+    tname = {v: k_ for k_, v in vars(Type).items() if isinstance(v, int)}[tc]
+    ops = ["LOR", "LXOR"] if tc == Type.BOOL else ["PLUS", "SECOND", "FIRST"]
+    accum = f"{ops[rng.integers(len(ops))]}_{tname}" if rng.random() < 0.5 else None
+    desc = ("R" if rng.random() < 0.3 else "") + (("S" if rng.random() < 0.5 else "") + ("C" if rng.random() < 0.4 else "") if M is not None else "") \
+        + ("T0" if a_tran else "") + ("T1" if b_tran else "")
+    return sr, A, B, C0, M, accum, desc, False
+
+
+@pytest.mark.parametrize("seed", range(100))
+def test_random_call_across_real_and_complex_types(gba, seed):
+    _check(gba, seed, *_mixed_case(seed))
