@@ -287,3 +287,19 @@ def test_complex_accum_and_mask_in_the_definition():
     p, v = oracle.mxm_spec(Matrix.sparse_empty(10, 10, t), Mk, None, "PLUS_TIMES_FC64", A, B, "S")
     mp = Mk.to_scipy().toarray() != 0
     assert np.array_equal(p, tp & mp) and np.array_equal(v[p], (a @ b)[p])
+
+
+def test_typecast_rules_across_real_and_complex():
+    """Source/GB_casting.h:211-446: a real value becomes the real part; a complex value gives its real part to every
+    real type (through the saturating rule for integers) and is true as a bool when either part is non-zero."""
+    z = np.array([1.5 - 2j, 0 + 3j, 0j, -300.7 + 1j, np.nan + 0j, 1e20 - 1j], np.complex128)
+    assert oracle.cast(z, Type.FC64, Type.FP64).tolist()[:4] == [1.5, 0.0, 0.0, -300.7]
+    assert oracle.cast(z, Type.FC64, Type.BOOL).tolist() == [True, True, False, True, True, True]
+    assert oracle.cast(z, Type.FC64, Type.INT8).tolist() == [1, 0, 0, -128, 0, 127]
+    assert oracle.cast(z, Type.FC64, Type.UINT8).tolist() == [1, 0, 0, 0, 0, 255]
+    got = oracle.cast(z[:4], Type.FC64, Type.FC32)
+    assert got.dtype == np.complex64 and np.array_equal(got, z[:4].astype(np.complex64))
+    r = np.array([2.5, -1.0, 0.0], np.float32)
+    assert np.array_equal(oracle.cast(r, Type.FP32, Type.FC64), np.array([2.5 + 0j, -1 + 0j, 0j]))
+    i = np.array([-3, 7], np.int16)
+    assert np.array_equal(oracle.cast(i, Type.INT16, Type.FC32), np.array([-3 + 0j, 7 + 0j], np.complex64))
