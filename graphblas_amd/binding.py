@@ -193,6 +193,9 @@ class _Lib:
             "gba_malloc": (vp, [C.c_size_t]), "gba_free": (None, [vp]),
             "gba_pool_set_limit": (i32, [C.c_size_t]), "gba_pool_release": (i32, []),
             "gba_pool_stats": (i32, [P(C.c_size_t), P(C.c_size_t)]),
+            "gba_host_malloc": (vp, [C.c_size_t]), "gba_host_calloc": (vp, [C.c_size_t, C.c_size_t]),
+            "gba_host_realloc": (vp, [vp, C.c_size_t]), "gba_host_free": (None, [vp]),
+            "gba_is_device_visible": (i32, [vp]),
             "gba_memcpy_h2d": (i32, [vp, vp, C.c_size_t]), "gba_memcpy_d2h": (i32, [vp, vp, C.c_size_t]),
             "gba_memset": (i32, [vp, C.c_int, C.c_size_t]), "gba_sync": (i32, []), "gba_stream": (vp, []),
             "gba_timer_start": (i32, []), "gba_timer_stop": (i32, [P(C.c_double)]),

@@ -15,6 +15,7 @@ namespace gba {
 
 // ------------------------------------------------------------------ errors --
 void set_error(const char *fmt, ...);
+std::string last_error();              // the calling thread's message (a copy: cleanup code may overwrite it)
 #define GBA_FAIL(code, ...) do { ::gba::set_error(__VA_ARGS__); return (code); } while (0)
 #define GBA_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     ::gba::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
@@ -213,6 +214,8 @@ gba_info sorted_copy(const gba_matrix *X, gba_matrix *out, std::vector<void *> &
 
 // stage a host-resident view into device memory (PCIe); owned[] collects the
 // buffers to free afterwards
-gba_info stage_to_device(const gba_matrix *in, gba_matrix *out, std::vector<void *> &owned);
+// device view of a host operand.  GBA_MEM_HOST: copied.  GBA_MEM_HOST_VISIBLE (pinned memory mapped into the
+// device's address space): read in place when `in_place` (each entry is read about once), copied otherwise.
+gba_info stage_to_device(const gba_matrix *in, gba_matrix *out, std::vector<void *> &owned, bool in_place = false);
 
 }  // namespace gba

@@ -251,7 +251,7 @@ static gba_info udt_writeback(gba_matrix *C, const gba_matrix *M, bool has_accum
 
 // set while a caller needs the product with sorted vectors (it goes on as the operand of another compiled dot
 // kernel): the pattern is sorted before the values are computed, so only indices move
-static bool g_udt_sorted_pattern = false;
+static thread_local bool g_udt_sorted_pattern = false;     // per host thread: concurrent calls do not see each other's switch
 
 static gba_matrix pattern_view(const gba_matrix &S) {
     gba_matrix v = S;
@@ -259,7 +259,7 @@ static gba_matrix pattern_view(const gba_matrix &S) {
     return v;
 }
 
-gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
+static gba_info mxm_udt_body(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
                  const gba_user_semiring *s, const gba_matrix *A, const gba_matrix *B, const gba_descriptor *desc,
                  gba_report *report) {
     GBA_OK(require_init());
@@ -389,6 +389,19 @@ gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, con
     }
     if (report) { rep.kernel_ms = timer.stop_ms(); *report = rep; }
     if (info == GBA_SUCCESS && C_was_hyper && is_sparse(C)) info = sparse_to_hyper(C);
+    return info;
+}
+
+gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
+                 const gba_user_semiring *s, const gba_matrix *A, const gba_matrix *B, const gba_descriptor *desc,
+                 gba_report *report) {
+    // a call that fails or is declined after a hypersparse C was expanded hands C back hypersparse, as it came
+    const bool C_was_hyper = C && is_hyper(C);
+    const gba_info info = mxm_udt_body(C, M, accum_name, accum_defn, s, A, B, desc, report);
+    if (info != GBA_SUCCESS && C_was_hyper && is_sparse(C) && C->mem == GBA_MEM_DEVICE) {
+        const std::string keep = last_error();
+        if (sparse_to_hyper(C) == GBA_SUCCESS) set_error("%s", keep.c_str());
+    }
     return info;
 }
 
@@ -549,9 +562,9 @@ gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
 
     struct Owned { std::vector<void *> v; ~Owned() { for (void *p : v) gba_free(p); } } own;
     gba_matrix Av, Bv, Mv, Cv = *C;
-    if (A->mem == GBA_MEM_HOST) GBA_OK(stage_to_device(A, &Av, own.v)); else Av = *A;
-    if (B->mem == GBA_MEM_HOST) GBA_OK(stage_to_device(B, &Bv, own.v)); else Bv = *B;
-    if (M) { if (M->mem == GBA_MEM_HOST) GBA_OK(stage_to_device(M, &Mv, own.v)); else Mv = *M; }
+    if (A->mem != GBA_MEM_DEVICE) GBA_OK(stage_to_device(A, &Av, own.v)); else Av = *A;
+    if (B->mem != GBA_MEM_DEVICE) GBA_OK(stage_to_device(B, &Bv, own.v)); else Bv = *B;
+    if (M) { if (M->mem != GBA_MEM_DEVICE) GBA_OK(stage_to_device(M, &Mv, own.v)); else Mv = *M; }
     gba_matrix Ac, Bc;
     if (Av.type != zt) { GBA_OK(cast_operand(&Av, zt, &Ac, own.v)); Av = Ac; }
     if (Bv.type != zt) { GBA_OK(cast_operand(&Bv, zt, &Bc, own.v)); Bv = Bc; }

@@ -841,9 +841,11 @@ static gba_info mxm_driver_sparse_C(Call k, gba_report *report, bool select_only
     gba_matrix Mdev, Adev, Bdev;
     if (C->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_NOT_IMPLEMENTED, "C must be a device view (mem == GBA_MEM_DEVICE)");
     const gba_matrix *M_user = k.M;
-    if (k.M && k.M->mem == GBA_MEM_HOST) { GBA_OK(stage_to_device(k.M, &Mdev, ex.owned)); k.M = &Mdev; }
-    if (k.A_in->mem == GBA_MEM_HOST) { GBA_OK(stage_to_device(k.A_in, &Adev, ex.owned)); k.A_in = &Adev; }
-    if (k.B_in->mem == GBA_MEM_HOST) { GBA_OK(stage_to_device(k.B_in, &Bdev, ex.owned)); k.B_in = &Bdev; }
+    // (a GBA_MEM_HOST_VISIBLE operand of a matrix-vector product is read in place: every entry is read about once)
+    const bool vector_call = (C->vdim == 1);
+    if (k.M && k.M->mem != GBA_MEM_DEVICE) { GBA_OK(stage_to_device(k.M, &Mdev, ex.owned, vector_call)); k.M = &Mdev; }
+    if (k.A_in->mem != GBA_MEM_DEVICE) { GBA_OK(stage_to_device(k.A_in, &Adev, ex.owned, vector_call)); k.A_in = &Adev; }
+    if (k.B_in->mem != GBA_MEM_DEVICE) { GBA_OK(stage_to_device(k.B_in, &Bdev, ex.owned, vector_call)); k.B_in = &Bdev; }
     (void)M_user;
     const gba_matrix *A_in = k.A_in, *B_in = k.B_in;
     // hypersparse operands are given to the kernels in sparse form (a pointer array over every vector);
@@ -1214,8 +1216,14 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
                            k.B_transpose, k.flipxy, k.C_replace, k.Mask_comp, k.Mask_struct, report);
     const bool C_was_hyper = k.C && is_hyper(k.C);
     const gba_info info = mxm_driver_sparse_C(k, report, select_only);
-    if (info != GBA_SUCCESS || !C_was_hyper || select_only || !is_sparse(k.C) || k.C->mem != GBA_MEM_DEVICE) return info;
-    return sparse_to_hyper(k.C);
+    if (!C_was_hyper || select_only || !is_sparse(k.C) || k.C->mem != GBA_MEM_DEVICE) return info;
+    if (info == GBA_SUCCESS) return sparse_to_hyper(k.C);
+    // A call that failed or was declined after C had been expanded hands C back as it came: hypersparse, with the
+    // same vectors and entries (a caller that falls back to the CPU library finds its C untouched).  The message of
+    // the failure is kept.
+    const std::string keep = last_error();
+    if (sparse_to_hyper(k.C) == GBA_SUCCESS) set_error("%s", keep.c_str());
+    return info;
 }
 
 }  // namespace gba

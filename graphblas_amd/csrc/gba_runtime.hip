@@ -11,6 +11,7 @@ namespace gba {
 
 // ------------------------------------------------------------------ errors --
 static thread_local char g_err[1024] = "";
+std::string last_error() { return std::string(g_err); }
 void set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -368,9 +369,27 @@ gba_info canonicalize(const gba_semiring *s, bool flipxy, int atype, int btype, 
     return GBA_SUCCESS;
 }
 
-gba_info stage_to_device(const gba_matrix *in, gba_matrix *out, std::vector<void *> &owned) {
+// device address of an array in pinned, mapped host memory (hipHostMalloc / gba_host_malloc)
+static gba_info device_alias(const void *host, void **dev) {
+    *dev = nullptr;
+    if (!host) return GBA_SUCCESS;
+    GBA_HIP(hipHostGetDevicePointer(dev, const_cast<void *>(host), 0));
+    return GBA_SUCCESS;
+}
+
+gba_info stage_to_device(const gba_matrix *in, gba_matrix *out, std::vector<void *> &owned, bool in_place) {
     *out = *in;
     if (in->mem == GBA_MEM_DEVICE) return GBA_SUCCESS;
+    if (in->mem == GBA_MEM_HOST_VISIBLE && in_place) {
+        // the kernels read the caller's arrays through the device's mapping of them: nothing is copied
+        GBA_OK(device_alias(in->p, (void **)&out->p));
+        GBA_OK(device_alias(in->h, (void **)&out->h));
+        GBA_OK(device_alias(in->i, (void **)&out->i));
+        GBA_OK(device_alias(in->x, &out->x));
+        GBA_OK(device_alias(in->b, (void **)&out->b));
+        out->mem = GBA_MEM_DEVICE;
+        return GBA_SUCCESS;
+    }
     hipStream_t st = ctx().stream;
     auto up = [&](const void *src, size_t bytes, void **dst) -> gba_info {
         *dst = nullptr;
@@ -545,6 +564,60 @@ gba_info gba_pool_set_limit(size_t nbytes) { pool().set_limit(nbytes); return GB
 gba_info gba_pool_stats(size_t *cached_bytes, size_t *live_bytes) {
     pool().stats(cached_bytes, live_bytes);
     return GBA_SUCCESS;
+}
+
+
+// ---- host memory the device can address: what GxB_init is given so that the arrays inside the CPU library's
+// handles can be handed to this library without a copy through pageable memory (the role of rmm_wrap's managed
+// pool for the reference's CUDA build, Source/GB_init.c:84-95; without XNACK a managed allocation stays in host
+// memory, so pinned + mapped host memory is the same thing stated plainly).  A 64-byte header in front of every
+// block keeps its size for realloc.
+namespace {
+struct HostHeader { uint64_t magic; uint64_t size; uint64_t pad[6]; };
+static_assert(sizeof(HostHeader) == 64, "payload stays 64-byte aligned");
+constexpr uint64_t HOST_MAGIC = 0x6762615f686f7374ull;      // "gba_host"
+HostHeader *host_header(void *p) { return reinterpret_cast<HostHeader *>(static_cast<char *>(p) - sizeof(HostHeader)); }
+}
+
+void *gba_host_malloc(size_t nbytes) {
+    void *raw = nullptr;
+    if (hipHostMalloc(&raw, nbytes + sizeof(HostHeader), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    HostHeader *h = static_cast<HostHeader *>(raw);
+    h->magic = HOST_MAGIC; h->size = nbytes;
+    return static_cast<char *>(raw) + sizeof(HostHeader);
+}
+void *gba_host_calloc(size_t count, size_t size) {
+    if (size != 0 && count > SIZE_MAX / size) return nullptr;
+    void *p = gba_host_malloc(count * size);
+    if (p) memset(p, 0, count * size);
+    return p;
+}
+void gba_host_free(void *p) {
+    if (!p) return;
+    HostHeader *h = host_header(p);
+    if (h->magic != HOST_MAGIC) return;                         // not a block of this allocator: left alone
+    h->magic = 0;
+    (void)hipHostFree(h);
+}
+void *gba_host_realloc(void *p, size_t nbytes) {
+    if (!p) return gba_host_malloc(nbytes);
+    HostHeader *h = host_header(p);
+    if (h->magic != HOST_MAGIC) return nullptr;
+    if (nbytes <= h->size) { h->size = nbytes; return p; }
+    void *q = gba_host_malloc(nbytes);
+    if (!q) return nullptr;                                     // the old block stays valid, like realloc
+    memcpy(q, p, h->size);
+    gba_host_free(p);
+    return q;
+}
+int gba_is_device_visible(const void *p) {
+    if (!p) return 0;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return (a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) ? 1 : 0;
 }
 
 gba_info gba_memcpy_h2d(void *dst, const void *src, size_t nbytes) {

@@ -1757,7 +1757,8 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                  int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
                  const int64_t *__restrict__ Cp, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx,
                  const int64_t *__restrict__ bstart, const int64_t *__restrict__ bounds,
-                 const int64_t *__restrict__ pstart, const uint2 *__restrict__ pwords, const int64_t *__restrict__ wbounds) {
+                 const int64_t *__restrict__ pstart, const uint2 *__restrict__ pwords, const int64_t *__restrict__ wbounds,
+                 const int64_t *__restrict__ vflops) {
     using Z = typename S::z_t; using ACC = typename S::acc_t;
     extern __shared__ __align__(16) unsigned char smem[];
     ACC *vals = reinterpret_cast<ACC *>(smem);
@@ -1791,6 +1792,14 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
         const int64_t pC0 = Cp[j];
         int64_t pC = pC0;
         const int64_t cj = Cp[j + 1] - pC;
+        // Offsets into the products of a panel are 32 bits wide.  All products of a vector whose multiply-adds stay
+        // below 2^31 fit whatever the panel's width; only a heavier vector keeps its hashed panels to PANEL_MAX_WIDTH
+        // indices (a run inside a panel is no longer than the panel is wide).
+#ifdef GBA_PANEL_CAPPED
+        const int64_t max_width = PANEL_MAX_WIDTH;
+#else
+        const int64_t max_width = (vflops[j] < ((int64_t)1 << 31)) ? cvlen : PANEL_MAX_WIDTH;
+#endif
         int64_t base = 0, iend = PANEL_INF;
         int64_t width = (cj > 0) ? (cvlen * NUM_PANEL_TARGET) / cj : cvlen;
         if (width > 4096) width = 4096;                 // the low indices are the dense end of a power-law vector
@@ -1828,7 +1837,7 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                 ranked = np >= 1 && np <= (int64_t)RANK_PPT * PANEL_THREADS;
             }
             const bool direct = !ranked && width <= NUM_PANEL_SLOTS;
-            int64_t lim = base + (ranked ? width : direct ? (int64_t)NUM_PANEL_SLOTS : ((width < PANEL_MAX_WIDTH) ? width : PANEL_MAX_WIDTH));
+            int64_t lim = base + (ranked ? width : direct ? (int64_t)NUM_PANEL_SLOTS : ((width < max_width) ? width : max_width));
             if (lim > iend) lim = iend;
             lim = uniform_i64(lim);
             const int64_t pend = (lim >= cvlen) ? PANEL_INF : lim;
@@ -2195,7 +2204,7 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
                            sr, ntasks, tasks.as<PanelTask>(), P.A, P.B, P.M, P.cvlen, P.maxdeg,
                            scratch.as<int64_t>(), next.as<unsigned long long>(), P.Cp, P.Ci, Cx, P.bstart, P.bounds,
-                           P.pstart, P.pwords, P.wbounds);
+                           P.pstart, P.pwords, P.wbounds, P.vflops);
         GBA_HIP(hipGetLastError());
         mark(4);
         GBA_HIP(hipMemcpyAsync(P.panel_stats, next.p, 112, hipMemcpyDeviceToHost, st));

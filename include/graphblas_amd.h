@@ -81,7 +81,8 @@ enum {
 
 enum { GBA_HYPERSPARSE = 1, GBA_SPARSE = 2, GBA_BITMAP = 4, GBA_FULL = 8 };
 
-enum { GBA_MEM_DEVICE = 0, GBA_MEM_HOST = 1 };
+enum { GBA_MEM_DEVICE = 0, GBA_MEM_HOST = 1,
+       GBA_MEM_HOST_VISIBLE = 2   /* host memory the device can address: gba_host_malloc, hipHostMalloc */ };
 
 /* descriptor values (GrB_Desc_Value) */
 enum {
@@ -122,7 +123,7 @@ typedef struct gba_matrix {
     int64_t  nzombies;
     gba_type type;
     int32_t  sparsity;   /* GBA_HYPERSPARSE | GBA_SPARSE | GBA_BITMAP | GBA_FULL */
-    int32_t  mem;        /* GBA_MEM_DEVICE | GBA_MEM_HOST */
+    int32_t  mem;        /* GBA_MEM_DEVICE | GBA_MEM_HOST | GBA_MEM_HOST_VISIBLE */
     bool     is_csc;
     bool     iso;
     bool     jumbled;    /* indices within a vector may be out of order */
@@ -203,6 +204,18 @@ void     gba_free(void *p);
 gba_info gba_pool_set_limit(size_t nbytes);
 gba_info gba_pool_release(void);           /* hipFree every idle block now */
 gba_info gba_pool_stats(size_t *idle_bytes, size_t *live_bytes);
+/* Host allocator whose blocks the device can address (pinned, mapped): the four functions GxB_init (mode, malloc,
+ * calloc, realloc, free) takes (Source/GxB_init.c:54-93; GPU mode installs rmm_wrap's, Source/GB_init.c:84-95).
+ * Arrays that come out of GxB_*_unpack_* are then views with mem = GBA_MEM_HOST_VISIBLE: the operands of
+ * gba_mxv / gba_vxm are read in place (no copy at all), those of gba_mxm are copied at the pinned-memory rate,
+ * and a result copied back into such a block needs no staging buffer.  Usable before gba_init; thread-safe.
+ * gba_is_device_visible (p): 1 when p lies in memory the device can address (any of these blocks, hipHostMalloc'd
+ * or registered memory, device memory), else 0. */
+void    *gba_host_malloc(size_t nbytes);
+void    *gba_host_calloc(size_t count, size_t size);
+void    *gba_host_realloc(void *p, size_t nbytes);
+void     gba_host_free(void *p);
+int      gba_is_device_visible(const void *p);
 gba_info gba_memcpy_h2d(void *dst, const void *src, size_t nbytes);
 gba_info gba_memcpy_d2h(void *dst, const void *src, size_t nbytes);
 gba_info gba_memset(void *dst, int byte, size_t nbytes);

@@ -8,14 +8,29 @@
  *   3. everything is packed back (GxB_Matrix_pack_*, GxB_Vector_pack_*, 9342-9760).
  * A semiring over one user-defined type goes to gba_mxm_udt with the strings the application gave to
  * GxB_Type_new / GxB_BinaryOp_new (shim_run_udt).
- * A call the device path does not take (casts to or from user-defined types, an iso-valued C,
- * an operator without a built-in code or definition, GBA_NOT_IMPLEMENTED from the library) goes to the next definition of the same
- * symbol, dlsym (RTLD_NEXT, ...): the CPU library, with its arguments untouched.
+ * A call the device path does not complete (casts to or from user-defined types, an iso-valued C, an operator
+ * without a built-in code or definition, and EVERY gba_info other than GBA_SUCCESS: not implemented, out of
+ * device memory, a compile error of a user-defined operator, a dimension or domain mismatch) goes to the next
+ * definition of the same symbol, dlsym (RTLD_NEXT, ...): the CPU library, with its arguments untouched -- C is
+ * only replaced after the device call has succeeded -- which then computes the result or reports the error with
+ * its own code and message.
+ *
+ * Aliased handles (Source/GB_mxm.c:48: any of C, Mask, A, B may be the same object; C = A*A, C<L> = L*L',
+ * q<!pi> = q'*A, d = d min.+ A) are taken: every distinct handle is moved out once and the roles share its view.
+ * The inputs are read from the host arrays, the output is built in device memory of its own, so an input that is
+ * also the output is read as it was on entry, which is the semantics of Source/GB_AxB_meta.c:500-509.
  *
  * Memory: the handles hold host arrays of the allocator given to GxB_init.  A, B and the mask are handed
- * over as host views (mem = GBA_MEM_HOST; the library stages them over PCIe).  C travels to the device
- * before the call and back after it, into arrays taken from that same allocator
- * (GxB_Global_Option_get_FUNCTION (GxB_MALLOC_FUNCTION, ...)), which is what GxB_*_pack_* requires.
+ * over as host views (mem = GBA_MEM_HOST; the library stages them over PCIe).  When the application gave
+ * GxB_init the library's own host allocator (gba_host_malloc / _calloc / _realloc / _free: pinned memory the
+ * device can address) the views are GBA_MEM_HOST_VISIBLE instead: GrB_mxv / GrB_vxm read their operands in place,
+ * GrB_mxm copies at the pinned rate.  C travels to the device before the call (nothing when it has no entries) and
+ * back after it, into arrays taken from the library's allocator (GxB_Global_Option_get_FUNCTION
+ * (GxB_MALLOC_FUNCTION, ...)), which is what GxB_*_pack_* requires.
+ *
+ * Threads: between unpack and pack a handle is empty, so the whole window is one critical section (a mutex): calls
+ * through the shim are serialised, and no other thread may use A, B, Mask or C during the call (the CPU library
+ * allows concurrent readers of A; behind this shim it does not hold).
  *
  * Build:  gcc -O2 -fPIC -shared -I<reference>/Include -I<repo>/include shim/grb_shim.c \
  *             -o libgrb_shim.so -L<repo>/graphblas_amd -lgraphblas_amd -ldl
@@ -24,6 +39,7 @@
 #include <dlfcn.h>
 #include <string.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include "GraphBLAS.h"
 #include "graphblas_amd.h"
 
@@ -134,7 +150,16 @@ typedef struct
     GrB_Index p_size, h_size, i_size, x_size, b_size ;
     int64_t vecp [2] ;          /* the two "pointers" of a sparse vector (a vector is an n-by-1 CSC matrix) */
     bool unpacked ;
+    size_t udt_size ;           /* bytes per value when v.type == GBA_UDT */
 } shim_operand ;
+
+/* do the handles hold arrays of gba_host_malloc (pinned memory the device can address)? */
+static bool shim_host_visible (void)
+{
+    void *(*lib_malloc) (size_t) = NULL ;
+    return (GxB_Global_Option_get_FUNCTION (GxB_MALLOC_FUNCTION, (void **) &lib_malloc) == GrB_SUCCESS
+        && lib_malloc == gba_host_malloc) ;
+}
 
 static bool shim_unpack_matrix (shim_operand *o, GrB_Matrix A)
 {
@@ -192,6 +217,7 @@ static bool shim_unpack_matrix (shim_operand *o, GrB_Matrix A)
             return (false) ;
     }
     v->iso = iso ; v->jumbled = jumbled ;
+    if (shim_host_visible ()) v->mem = GBA_MEM_HOST_VISIBLE ;
     o->unpacked = true ;
     return (true) ;
 }
@@ -228,6 +254,8 @@ static bool shim_unpack_vector (shim_operand *o, GrB_Vector w)
     }
     v->nvals = (int64_t) nvals ;
     v->iso = iso ; v->jumbled = jumbled ;
+    /* (the two pointers of a sparse vector live in this struct, in ordinary memory: such a view is copied) */
+    if (shim_host_visible () && v->p == NULL) v->mem = GBA_MEM_HOST_VISIBLE ;
     o->unpacked = true ;
     return (true) ;
 }
@@ -274,13 +302,11 @@ static GrB_Info shim_pack (shim_operand *o)
 
 /* --------------------------------------------------------------- the output -- */
 
-static size_t shim_udt_size = 0 ;       /* bytes per value of the GBA_UDT views while a user-defined call is running */
-
-static size_t shim_type_size (gba_type t)
+static size_t shim_type_size (gba_type t, size_t udt_size)
 {
     switch (t)
     {
-        case GBA_UDT : return (shim_udt_size) ;
+        case GBA_UDT : return (udt_size) ;
         case GBA_BOOL : case GBA_INT8 : case GBA_UINT8 : return (1) ;
         case GBA_INT16 : case GBA_UINT16 : return (2) ;
         case GBA_INT32 : case GBA_UINT32 : case GBA_FP32 : return (4) ;
@@ -290,9 +316,9 @@ static size_t shim_type_size (gba_type t)
 }
 
 /* bytes of each array of a view */
-static void shim_sizes (const gba_matrix *v, size_t *pb, size_t *hb, size_t *ib, size_t *xb, size_t *bb)
+static void shim_sizes (const gba_matrix *v, size_t udt_size, size_t *pb, size_t *hb, size_t *ib, size_t *xb, size_t *bb)
 {
-    const size_t dense = (size_t) v->vlen * (size_t) v->vdim, ts = shim_type_size (v->type) ;
+    const size_t dense = (size_t) v->vlen * (size_t) v->vdim, ts = shim_type_size (v->type, udt_size) ;
     const bool sparse = (v->sparsity == GBA_SPARSE || v->sparsity == GBA_HYPERSPARSE) ;
     (*pb) = sparse ? (size_t) (v->nvec + 1) * 8 : 0 ;
     (*hb) = (v->sparsity == GBA_HYPERSPARSE) ? (size_t) v->nvec * 8 : 0 ;
@@ -302,13 +328,13 @@ static void shim_sizes (const gba_matrix *v, size_t *pb, size_t *hb, size_t *ib,
 }
 
 /* device copy of the host view of C (the library wants its in/out operand on the device) */
-static bool shim_upload (gba_matrix *dev, const gba_matrix *host)
+static bool shim_upload (gba_matrix *dev, const gba_matrix *host, size_t udt_size)
 {
     (*dev) = (*host) ;
     dev->mem = GBA_MEM_DEVICE ;
     dev->p = NULL ; dev->h = NULL ; dev->i = NULL ; dev->x = NULL ; dev->b = NULL ;
     size_t pb, hb, ib, xb, bb ;
-    shim_sizes (host, &pb, &hb, &ib, &xb, &bb) ;
+    shim_sizes (host, udt_size, &pb, &hb, &ib, &xb, &bb) ;
     const void *src [5] = {host->p, host->h, host->i, host->x, host->b} ;
     void **dst [5] = {(void **) &(dev->p), (void **) &(dev->h), (void **) &(dev->i), &(dev->x), (void **) &(dev->b)} ;
     const size_t nb [5] = {pb, hb, ib, xb, bb} ;
@@ -335,7 +361,7 @@ static bool shim_download (shim_operand *c, gba_matrix *dev)
     gba_matrix h = (*dev) ;
     h.mem = GBA_MEM_HOST ; h.p = NULL ; h.h = NULL ; h.i = NULL ; h.x = NULL ; h.b = NULL ;
     size_t pb, hb, ib, xb, bb ;
-    shim_sizes (dev, &pb, &hb, &ib, &xb, &bb) ;
+    shim_sizes (dev, c->udt_size, &pb, &hb, &ib, &xb, &bb) ;
     const void *src [5] = {dev->p, dev->h, dev->i, dev->x, dev->b} ;
     void **dst [5] = {(void **) &(h.p), (void **) &(h.h), (void **) &(h.i), &(h.x), (void **) &(h.b)} ;
     const size_t need [5] = {pb, hb, ib, xb, bb} ;                          /* bytes to copy */
@@ -374,17 +400,39 @@ static bool shim_download (shim_operand *c, gba_matrix *dev)
 
 /* ------------------------------------------------------------------ the call -- */
 
+/* The operands of one call.  Every DISTINCT handle is moved out of its object once (ops [0 .. nops)); the four
+ * roles point into that list, so GrB_mxm (C, L, NULL, sr, L, L, desc) has two operands and four roles. */
 typedef struct
 {
-    shim_operand c, m, a, b ;
+    shim_operand ops [4] ;
+    int nops ;
+    shim_operand *c, *m, *a, *b ;
     bool has_mask ;
 } shim_call ;
 
-static void shim_repack_inputs (shim_call *k)
+static shim_operand *shim_role_matrix (shim_call *k, GrB_Matrix A)
 {
-    shim_pack (&(k->a)) ; shim_pack (&(k->b)) ;
-    if (k->has_mask) shim_pack (&(k->m)) ;
+    for (int q = 0 ; q < k->nops ; q++) if (k->ops [q].A == A && A != NULL) return (&(k->ops [q])) ;
+    if (!shim_unpack_matrix (&(k->ops [k->nops]), A)) return (NULL) ;       /* (nothing was moved when this fails) */
+    return (&(k->ops [k->nops++])) ;
 }
+
+static shim_operand *shim_role_vector (shim_call *k, GrB_Vector w)
+{
+    for (int q = 0 ; q < k->nops ; q++) if (k->ops [q].w == w && w != NULL) return (&(k->ops [q])) ;
+    if (!shim_unpack_vector (&(k->ops [k->nops]), w)) return (NULL) ;
+    return (&(k->ops [k->nops++])) ;
+}
+
+/* every handle gets its arrays back; false when one could not be restored (the object is then empty) */
+static bool shim_pack_all (shim_call *k)
+{
+    bool ok = true ;
+    for (int q = 0 ; q < k->nops ; q++) ok = (shim_pack (&(k->ops [q])) == GrB_SUCCESS) && ok ;
+    return (ok) ;
+}
+
+static pthread_mutex_t shim_lock = PTHREAD_MUTEX_INITIALIZER ;      /* a handle is empty between unpack and pack */
 
 static bool shim_device_ready (void)
 {
@@ -398,18 +446,20 @@ static bool shim_device_ready (void)
     return (true) ;
 }
 
-static bool shim_run_udt (GrB_Info *result, int which, shim_call *k, const GrB_BinaryOp accum,
+static bool shim_run_udt (int which, shim_call *k, const GrB_BinaryOp accum,
     const GrB_Semiring semiring, const GrB_Descriptor desc) ;
 
-/* true: handled on the device, *result is the GrB_Info to return.  false: nothing was changed, the caller
-   passes the call on to the CPU library. */
-static bool shim_run (GrB_Info *result, int which, shim_call *k, const GrB_BinaryOp accum,
+/* true: the result was computed on the device and C holds it.  false: C, A, B and the mask are as they came and the
+   caller passes the call on to the CPU library -- also after a device-side failure of any kind (out of memory, a
+   compile error, an unsupported case, a dimension mismatch): the CPU library then computes the result or reports the
+   error with its own code and message. */
+static bool shim_run (int which, shim_call *k, const GrB_BinaryOp accum,
     const GrB_Semiring semiring, const GrB_Descriptor desc)
 {
     gba_semiring s ; gba_binop acc ; gba_descriptor d ;
-    if (k->c.v.type == GBA_UDT) return (shim_run_udt (result, which, k, accum, semiring, desc)) ;
+    if (k->c->v.type == GBA_UDT) return (shim_run_udt (which, k, accum, semiring, desc)) ;
     if (semiring == NULL || !shim_semiring (&s, semiring)) return (false) ;
-    if (k->a.v.type == GBA_UDT || k->b.v.type == GBA_UDT) return (false) ;     /* a built-in semiring on user-typed operands */
+    if (k->a->v.type == GBA_UDT || k->b->v.type == GBA_UDT) return (false) ;     /* a built-in semiring on user-typed operands */
     acc.op = GBA_NOP ; acc.type = s.ztype ;
     if (accum != NULL)
     {
@@ -417,20 +467,19 @@ static bool shim_run (GrB_Info *result, int which, shim_call *k, const GrB_Binar
         if (!shim_binop (&(acc.op), &ax, &ay, &(acc.type), accum)) return (false) ;
     }
     shim_descriptor (&d, desc) ;
-    if (k->has_mask && k->m.v.type == GBA_UDT && !(d.mask == GBA_STRUCTURE || d.mask == GBA_COMP_STRUCTURE))
+    if (k->has_mask && k->m->v.type == GBA_UDT && !(d.mask == GBA_STRUCTURE || d.mask == GBA_COMP_STRUCTURE))
         return (false) ;                                /* a user-typed mask read by value: the CPU library's error */
     if (!shim_device_ready ()) return (false) ;
     gba_matrix cdev ;
-    if (k->c.v.iso || !shim_upload (&cdev, &(k->c.v))) return (false) ;
-    const gba_matrix *m = k->has_mask ? &(k->m.v) : NULL ;
+    if (k->c->v.iso || !shim_upload (&cdev, &(k->c->v), 0)) return (false) ;
+    /* the inputs stay host views (an input that is also the output is read as it was on entry); C is cdev */
+    const gba_matrix *m = k->has_mask ? &(k->m->v) : NULL ;
     gba_info info ;
-    if (which == 0) info = gba_mxm (&cdev, m, accum ? &acc : NULL, &s, &(k->a.v), &(k->b.v), &d, NULL) ;
-    else if (which == 1) info = gba_vxm (&cdev, m, accum ? &acc : NULL, &s, &(k->a.v), &(k->b.v), &d, NULL) ;
-    else info = gba_mxv (&cdev, m, accum ? &acc : NULL, &s, &(k->a.v), &(k->b.v), &d, NULL) ;
-    bool taken = (info != GBA_NOT_IMPLEMENTED && info != GBA_NO_VALUE) ;
-    if (taken && info == GBA_SUCCESS) taken = shim_download (&(k->c), &cdev) ;
+    if (which == 0) info = gba_mxm (&cdev, m, accum ? &acc : NULL, &s, &(k->a->v), &(k->b->v), &d, NULL) ;
+    else if (which == 1) info = gba_vxm (&cdev, m, accum ? &acc : NULL, &s, &(k->a->v), &(k->b->v), &d, NULL) ;
+    else info = gba_mxv (&cdev, m, accum ? &acc : NULL, &s, &(k->a->v), &(k->b->v), &d, NULL) ;
+    const bool taken = (info == GBA_SUCCESS) && shim_download (k->c, &cdev) ;
     gba_matrix_free_content (&cdev) ;
-    if (taken) (*result) = (GrB_Info) info ;          /* the codes are the reference's (GrB_Info) */
     return (taken) ;
 }
 
@@ -473,18 +522,18 @@ static bool shim_binop_is_over (GrB_BinaryOp op, int32_t code)
 
 /* C<M> = accum (C, A*B) (which == 0) or w<m> = accum (w, A*u) (which == 2) over a semiring of one user-defined
  * type.  Same contract as shim_run. */
-static bool shim_run_udt (GrB_Info *result, int which, shim_call *k, const GrB_BinaryOp accum,
+static bool shim_run_udt (int which, shim_call *k, const GrB_BinaryOp accum,
     const GrB_Semiring semiring, const GrB_Descriptor desc)
 {
     if (which == 1 || semiring == NULL) return (false) ;           /* vxm flips the multiplier: left to the CPU */
-    if (k->c.v.type != GBA_UDT || k->a.v.type != GBA_UDT || k->b.v.type != GBA_UDT || k->c.v.iso) return (false) ;
+    if (k->c->v.type != GBA_UDT || k->a->v.type != GBA_UDT || k->b->v.type != GBA_UDT || k->c->v.iso) return (false) ;
     GrB_Type tc, ta, tb ;
-    if (!shim_operand_type (&tc, &(k->c)) || !shim_operand_type (&ta, &(k->a)) || !shim_operand_type (&tb, &(k->b))
+    if (!shim_operand_type (&tc, k->c) || !shim_operand_type (&ta, k->a) || !shim_operand_type (&tb, k->b)
         || ta != tc || tb != tc) return (false) ;
     gba_descriptor d ;
     shim_descriptor (&d, desc) ;
     const bool structural = (d.mask == GBA_STRUCTURE || d.mask == GBA_COMP_STRUCTURE) ;
-    if (k->has_mask && k->m.v.type == GBA_UDT && !structural) return (false) ;
+    if (k->has_mask && k->m->v.type == GBA_UDT && !structural) return (false) ;
     GrB_Monoid monoid ; GrB_BinaryOp add, mult ;
     SHIM_OK (GxB_Semiring_add (&monoid, semiring)) ;
     SHIM_OK (GxB_Monoid_operator (&add, monoid)) ;
@@ -499,31 +548,46 @@ static bool shim_run_udt (GrB_Info *result, int which, shim_call *k, const GrB_B
         accum ? shim_binop_string (accum, GxB_JIT_C_NAME) : NULL, accum ? shim_binop_string (accum, GxB_JIT_C_DEFINITION) : NULL } ;
     bool taken = true ;
     for (int q = 0 ; q < (accum ? 8 : 6) ; q++) taken = taken && (str [q] != NULL) ;
-    gba_matrix cdev, adev, bdev, mdev ;
-    memset (&cdev, 0, sizeof (cdev)) ; memset (&adev, 0, sizeof (adev)) ;
-    memset (&bdev, 0, sizeof (bdev)) ; memset (&mdev, 0, sizeof (mdev)) ;
+    /* device copies, one per distinct operand (the compiled kernels want device views); C gets one of its own */
+    gba_matrix dev [4], cdev ;
+    memset (dev, 0, sizeof (dev)) ; memset (&cdev, 0, sizeof (cdev)) ;
+    bool up [4] = {false, false, false, false} ;
     if (taken && !shim_device_ready ()) taken = false ;
     if (taken)
     {
-        shim_udt_size = tsize ;
-        taken = shim_upload (&cdev, &(k->c.v)) && shim_upload (&adev, &(k->a.v)) && shim_upload (&bdev, &(k->b.v))
-            && (!k->has_mask || shim_upload (&mdev, &(k->m.v))) ;
+        k->c->udt_size = tsize ;
+        taken = shim_upload (&cdev, &(k->c->v), tsize) ;
+        const shim_operand *roles [3] = { k->a, k->b, k->has_mask ? k->m : NULL } ;
+        for (int r = 0 ; r < 3 && taken ; r++)
+        {
+            if (roles [r] == NULL) continue ;
+            const int q = (int) (roles [r] - k->ops) ;
+            if (!up [q]) { taken = shim_upload (&(dev [q]), &(roles [r]->v), tsize) ; up [q] = taken ; }
+        }
     }
     if (taken)
     {
         gba_user_semiring us ;
         us.type_name = str [0] ; us.type_defn = str [1] ; us.type_size = tsize ;
         us.add_name = str [2] ; us.add_defn = str [3] ; us.mult_name = str [4] ; us.mult_defn = str [5] ;
-        const gba_info info = gba_mxm_udt (&cdev, k->has_mask ? &mdev : NULL, str [6], str [7], &us, &adev, &bdev, &d, NULL) ;
-        taken = (info != GBA_NOT_IMPLEMENTED && info != GBA_NO_VALUE) ;
-        if (taken && info == GBA_SUCCESS) taken = shim_download (&(k->c), &cdev) ;
-        if (taken) (*result) = (GrB_Info) info ;
+        const gba_info info = gba_mxm_udt (&cdev, k->has_mask ? &(dev [k->m - k->ops]) : NULL, str [6], str [7], &us,
+            &(dev [k->a - k->ops]), &(dev [k->b - k->ops]), &d, NULL) ;
+        taken = (info == GBA_SUCCESS) && shim_download (k->c, &cdev) ;
     }
-    gba_matrix_free_content (&cdev) ; gba_matrix_free_content (&adev) ;
-    gba_matrix_free_content (&bdev) ; gba_matrix_free_content (&mdev) ;
+    gba_matrix_free_content (&cdev) ;
+    for (int q = 0 ; q < 4 ; q++) if (up [q]) gba_matrix_free_content (&(dev [q])) ;
     for (int q = 0 ; q < 8 ; q++) free (str [q]) ;
     return (taken) ;
 }
+
+/* after the multiply: everything goes back into its handle.  A handle that cannot be restored is a lost object:
+   the call then reports GrB_PANIC instead of going on with an empty operand. */
+#define SHIM_FINISH(call_next)                                              \
+    const bool packed = shim_pack_all (&k) ;                                \
+    pthread_mutex_unlock (&shim_lock) ;                                     \
+    if (!packed) return (GrB_PANIC) ;                                       \
+    if (ok) return (GrB_SUCCESS) ;                                          \
+    return (next ? (call_next) : GrB_PANIC) ;
 
 GrB_Info GrB_mxm (GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
     const GrB_Matrix A, const GrB_Matrix B, const GrB_Descriptor desc)
@@ -531,21 +595,15 @@ GrB_Info GrB_mxm (GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum,
     static shim_mxm_f next = NULL ;
     if (next == NULL) next = (shim_mxm_f) dlsym (RTLD_NEXT, "GrB_mxm") ;
     (void) shim_check_mxm ;
-    /* aliased handles cannot be moved out twice: those calls stay on the CPU */
-    bool ok = (C != NULL && A != NULL && B != NULL && C != A && C != B && A != B && C != Mask && Mask != A && Mask != B) ;
+    if (C == NULL || A == NULL || B == NULL) return (next ? next (C, Mask, accum, semiring, A, B, desc) : GrB_NULL_POINTER) ;
     shim_call k ; memset (&k, 0, sizeof (k)) ;
-    GrB_Info result = GrB_SUCCESS ;
-    if (ok)
-    {
-        k.has_mask = (Mask != NULL) ;
-        ok = shim_unpack_matrix (&(k.a), A) && shim_unpack_matrix (&(k.b), B)
-            && (!k.has_mask || shim_unpack_matrix (&(k.m), Mask)) && shim_unpack_matrix (&(k.c), C) ;
-        if (ok) ok = shim_run (&result, 0, &k, accum, semiring, desc) ;
-        shim_repack_inputs (&k) ;
-        shim_pack (&(k.c)) ;
-    }
-    if (ok) return (result) ;
-    return (next ? next (C, Mask, accum, semiring, A, B, desc) : GrB_PANIC) ;
+    pthread_mutex_lock (&shim_lock) ;
+    k.has_mask = (Mask != NULL) ;
+    /* C first: when it is also an input, that input reads the view made here */
+    bool ok = ((k.c = shim_role_matrix (&k, C)) != NULL) && ((k.a = shim_role_matrix (&k, A)) != NULL)
+        && ((k.b = shim_role_matrix (&k, B)) != NULL) && (!k.has_mask || (k.m = shim_role_matrix (&k, Mask)) != NULL) ;
+    if (ok) ok = shim_run (0, &k, accum, semiring, desc) ;
+    SHIM_FINISH (next (C, Mask, accum, semiring, A, B, desc))
 }
 
 GrB_Info GrB_vxm (GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
@@ -554,20 +612,14 @@ GrB_Info GrB_vxm (GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum,
     static shim_vxm_f next = NULL ;
     if (next == NULL) next = (shim_vxm_f) dlsym (RTLD_NEXT, "GrB_vxm") ;
     (void) shim_check_vxm ;
-    bool ok = (w != NULL && u != NULL && A != NULL && w != u && w != mask && mask != u) ;
+    if (w == NULL || u == NULL || A == NULL) return (next ? next (w, mask, accum, semiring, u, A, desc) : GrB_NULL_POINTER) ;
     shim_call k ; memset (&k, 0, sizeof (k)) ;
-    GrB_Info result = GrB_SUCCESS ;
-    if (ok)
-    {
-        k.has_mask = (mask != NULL) ;
-        ok = shim_unpack_vector (&(k.a), u) && shim_unpack_matrix (&(k.b), A)
-            && (!k.has_mask || shim_unpack_vector (&(k.m), mask)) && shim_unpack_vector (&(k.c), w) ;
-        if (ok) ok = shim_run (&result, 1, &k, accum, semiring, desc) ;
-        shim_repack_inputs (&k) ;
-        shim_pack (&(k.c)) ;
-    }
-    if (ok) return (result) ;
-    return (next ? next (w, mask, accum, semiring, u, A, desc) : GrB_PANIC) ;
+    pthread_mutex_lock (&shim_lock) ;
+    k.has_mask = (mask != NULL) ;
+    bool ok = ((k.c = shim_role_vector (&k, w)) != NULL) && ((k.a = shim_role_vector (&k, u)) != NULL)
+        && ((k.b = shim_role_matrix (&k, A)) != NULL) && (!k.has_mask || (k.m = shim_role_vector (&k, mask)) != NULL) ;
+    if (ok) ok = shim_run (1, &k, accum, semiring, desc) ;
+    SHIM_FINISH (next (w, mask, accum, semiring, u, A, desc))
 }
 
 GrB_Info GrB_mxv (GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
@@ -576,18 +628,12 @@ GrB_Info GrB_mxv (GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum,
     static shim_mxv_f next = NULL ;
     if (next == NULL) next = (shim_mxv_f) dlsym (RTLD_NEXT, "GrB_mxv") ;
     (void) shim_check_mxv ;
-    bool ok = (w != NULL && u != NULL && A != NULL && w != u && w != mask && mask != u) ;
+    if (w == NULL || u == NULL || A == NULL) return (next ? next (w, mask, accum, semiring, A, u, desc) : GrB_NULL_POINTER) ;
     shim_call k ; memset (&k, 0, sizeof (k)) ;
-    GrB_Info result = GrB_SUCCESS ;
-    if (ok)
-    {
-        k.has_mask = (mask != NULL) ;
-        ok = shim_unpack_matrix (&(k.a), A) && shim_unpack_vector (&(k.b), u)
-            && (!k.has_mask || shim_unpack_vector (&(k.m), mask)) && shim_unpack_vector (&(k.c), w) ;
-        if (ok) ok = shim_run (&result, 2, &k, accum, semiring, desc) ;
-        shim_repack_inputs (&k) ;
-        shim_pack (&(k.c)) ;
-    }
-    if (ok) return (result) ;
-    return (next ? next (w, mask, accum, semiring, A, u, desc) : GrB_PANIC) ;
+    pthread_mutex_lock (&shim_lock) ;
+    k.has_mask = (mask != NULL) ;
+    bool ok = ((k.c = shim_role_vector (&k, w)) != NULL) && ((k.a = shim_role_matrix (&k, A)) != NULL)
+        && ((k.b = shim_role_vector (&k, u)) != NULL) && (!k.has_mask || (k.m = shim_role_vector (&k, mask)) != NULL) ;
+    if (ok) ok = shim_run (2, &k, accum, semiring, desc) ;
+    SHIM_FINISH (next (w, mask, accum, semiring, A, u, desc))
 }

@@ -416,3 +416,30 @@ def test_costly_sparse_mask_is_discarded_and_applied_afterwards(gba, desc):
     assert_dense_same(dC.to_host(), p, v, exact=True, what=desc)
     for d in (dA, dB, dM, dC):
         d.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("failure", ["dimension", "accum_type"])
+def test_a_hypersparse_C_is_untouched_by_a_call_that_fails(gba, failure):
+    """A call that fails validation (or is declined) must hand a hypersparse C back as it came -- hypersparse, the
+    same list of vectors, the same entries -- so that a caller which falls back to the CPU library finds its C
+    unchanged (the front end expands a hypersparse C to a pointer per vector before it works on it)."""
+    g = gba
+    rng = np.random.default_rng(5)
+    n = 300
+    S = sp.random(n, n, density=0.002, format="csr", random_state=7, dtype=np.float64)
+    C0 = Matrix.from_scipy(S, type=Type.FP64).to_hyper()
+    assert C0.nvec < n // 2
+    A = Matrix.from_scipy(sp.random(n + (1 if failure == "dimension" else 0), n, density=0.02, format="csr", random_state=8), type=Type.FP64)
+    B = Matrix.from_scipy(sp.random(n, n, density=0.02, format="csr", random_state=9), type=Type.FP64)
+    dC, dA, dB = C0.to_device(), A.to_device(), B.to_device()
+    accum = "PLUS_INT32" if failure == "accum_type" else None
+    with pytest.raises(GrbError) as err:
+        g.mxm(dC, None, accum, "PLUS_TIMES_FP64", dA, dB, None)
+    assert err.value.info == (Info.DIMENSION_MISMATCH if failure == "dimension" else Info.NOT_IMPLEMENTED)
+    back = dC.to_host()
+    assert back.sparsity == Sparsity.HYPERSPARSE and back.nvec == C0.nvec
+    assert np.array_equal(back.h, C0.h) and np.array_equal(back.p, C0.p)
+    assert np.array_equal(back.i, C0.i) and np.array_equal(back.x, C0.x)
+    for d in (dC, dA, dB):
+        d.free()

@@ -41,6 +41,7 @@ def test_shim_defines_the_three_entry_points_with_the_header_prototypes(shim_obj
 
 def test_shim_needs_only_public_interfaces(shim_object):
     libc = {"dlsym", "getenv", "strcmp", "strncmp", "strncpy", "strrchr", "strtol", "atoi", "memset", "memcpy", "malloc", "free", "strlen",
+            "pthread_mutex_lock", "pthread_mutex_unlock",
             "__stack_chk_fail", "_GLOBAL_OFFSET_TABLE_"}
     stray = [s for s in _symbols(shim_object, "-u") if not (s.startswith(("GrB_", "GxB_", "gba_")) or s in libc)]
     assert not stray, stray
@@ -58,5 +59,18 @@ def test_shim_needs_only_public_interfaces(shim_object):
 
 def test_shim_links_as_a_shared_library(shim_object, tmp_path):
     so = str(tmp_path / "libgrb_shim.so")
-    r = subprocess.run(["gcc", "-shared", shim_object, "-o", so, "-ldl"], capture_output=True, text=True)
+    r = subprocess.run(["gcc", "-shared", shim_object, "-o", so, "-ldl", "-lpthread"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_the_test_double_compiles_against_the_header_and_serves_the_shim(shim_object, tmp_path):
+    """tests/fake_grb.c stands in for the CPU library when the shim is executed (tests/test_gpu_shim_run.py).  Its
+    definitions take their prototypes from the reference's header (a mismatch does not compile), and every GrB_ / GxB_
+    function the shim calls is defined there, so the shim links against it with nothing unresolved but the gba_ C ABI."""
+    fake = str(tmp_path / "libfake_grb.so")
+    r = subprocess.run(["gcc", "-std=c11", "-O2", "-fPIC", "-Wall", "-Wextra", "-Werror", "-shared", "-I" + REF_INCLUDE,
+                        os.path.join(ROOT, "tests", "fake_grb.c"), "-o", fake], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    provided = set(_symbols(fake, "--defined-only"))
+    needed = [s for s in _symbols(shim_object, "-u") if s.startswith(("GrB_", "GxB_"))]
+    assert not [s for s in needed if s not in provided]
