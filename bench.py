@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--chunk-flops", type=float, default=6e9, help="max multiply-adds per row chunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the row-sum check of every chunk in the first warm-up step")
     ap.add_argument("--no-spmv", action="store_true", help="leave out the SpMV leg reported beside the headline")
     ap.add_argument("--cpu-flops", type=float, default=8e9, help="multiply-adds in the CPU baseline sample")
     return ap.parse_args()
@@ -98,7 +99,7 @@ def main():
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     import graphblas_amd as g
-    from graphblas_amd import gen, Type, DeviceMatrix
+    from graphblas_amd import gen, Type, DeviceMatrix, Matrix
     from graphblas_amd.dist import row_flops, split_by_flops, chunks_by_flops, RowBlockExchange
     from graphblas_amd.binding import gba_matrix
     g.init(local_rank)
@@ -154,13 +155,47 @@ def main():
     stats = {"phase_ms": np.zeros(8), "cnz": 0, "bins": np.zeros(4, np.int64), "bin_cnz": np.zeros(4, np.int64),
              "bin_bnz": np.zeros(4, np.int64), "bin_madds": np.zeros(4, np.int64), "launches": 0}
 
-    def step(collect):
+    # Correctness of what is timed, checked on every row chunk of one untimed step: the row sums of the chunk of C
+    # against A_I (A v) computed on the host in fp64, for v = 1 and for a random positive v.  A missing, doubled or
+    # misplaced entry, or a wrong value, shows in one of the two; all terms are positive, so the two evaluations of a
+    # row sum of m products agree within 2 (m + 1) u relative (tests/util.py::assert_sums_within_bound).
+    verify = {"chunks": 0, "rows": 0, "worst_ratio": 0.0, "ok": True, "nnz_ok": True}
+    vecs = [np.ones(n), np.random.default_rng(7).random(n) + 0.5]
+    checks = None
+
+    def verify_chunk(Cc, lo, hi, cnz):
+        nonlocal checks
+        if checks is None:
+            S = A.to_scipy()
+            checks = [(Matrix.full_vector(v).to_device(), S, S @ v) for v in vecs]
+        u = np.finfo(np.float64).eps / 2
+        if Cc.view.nvals != cnz or cnz <= 0:
+            verify["nnz_ok"] = False
+        for dv, S, Av in checks:
+            y = Matrix.full_vector(np.zeros(hi - lo)).to_device()
+            g.mxv(y, None, "PLUS_FP64", sr, Cc, dv)                      # y = C_I v on the device (dot4)
+            got = y.to_host().x
+            y.free()
+            want = S[lo:hi] @ Av
+            m = rf[lo:hi].astype(np.float64)
+            live = want > 0
+            ratio = np.zeros(hi - lo)
+            ratio[live] = np.abs(got[live] - want[live]) / (2 * (m[live] + 1) * u * want[live])
+            if np.any(got[~live] != 0) or (live.any() and ratio.max() > 1.0):
+                verify["ok"] = False
+            verify["worst_ratio"] = max(verify["worst_ratio"], float(ratio.max()) if live.any() else 0.0)
+        verify["chunks"] += 1
+        verify["rows"] += hi - lo
+
+    def step(collect, check=False):
         exchange()
         torch.cuda.synchronize()
         for lo, hi in my_chunks:
             Cc = DeviceMatrix.empty(hi - lo, n, Type.FP64)
             tw = time.perf_counter()
             rep = g.mxm(Cc, None, None, sr, view_rows(lo, hi), Bfull, None)
+            if check:
+                verify_chunk(Cc, lo, hi, rep.cnz)
             if os.environ.get("GBA_BENCH_DEBUG"):
                 tw1 = time.perf_counter()
                 Cc.free(); g.sync()
@@ -186,8 +221,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    for w in range(args.warmup):
+        step(False, check=(w == 0 and not args.no_verify))
+    checked = args.warmup > 0 and not args.no_verify
+    if checks is not None:
+        for dv, _, _ in checks:
+            dv.free()
+        checks = None
     fence()
     t1 = time.perf_counter()
     for _ in range(args.steps):
@@ -204,6 +244,11 @@ def main():
         cnz_all = int(agg.item()) // max(args.steps, 1)
     else:
         cnz_all = stats["cnz"] // max(args.steps, 1)
+    failed = checked and not (verify["ok"] and verify["nnz_ok"])
+    if multi:                                            # one failing rank fails the job
+        bad = torch.tensor([1 if failed else 0], dtype=torch.int64, device=rdev)
+        dist.all_reduce(bad)
+        failed = bool(bad.item())
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
@@ -245,6 +290,11 @@ def main():
                          "kernel_multiply_adds_per_launch": int(stats["bin_madds"][k] // launches)},
             "panels_rank0": [int(stats.get("panels", 0)) // max(args.steps, 1), int(stats.get("panels_redone", 0)) // max(args.steps, 1)],
             "generate_s": round(gen_s, 1),
+            # every row chunk of the first warm-up step, on this rank: row sums C_I v against A_I (A v) in fp64 on the
+            # host for v = 1 and a random v, within 2 (m + 1) u of each other for a row of m products; null = not run
+            "verified": ((not failed) if checked else None),
+            "verification": {"chunks": verify["chunks"], "rows": verify["rows"], "vectors": len(vecs),
+                             "worst_error_over_bound": round(verify["worst_ratio"], 4)},
         }
         if world == 1 and not args.no_spmv:                   # second workload of the path, outside the timed region
             out["spmv"] = spmv_leg(g, torch, A, Bp, Bi, Bx, dev, args)
@@ -254,6 +304,8 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit("bench.py: the product failed its row-sum check (see \"verification\")")
 
 
 def spmv_leg(g, torch, A, Bp, Bi, Bx, dev, args, iters=20):

@@ -730,9 +730,12 @@ static gba_info run_dot(gba_matrix *T, const Call &k, const gba_matrix *C_in, co
     Canon c;
     GBA_OK(canonicalize(&k.semiring, flipxy, A->type, B->type, &c));
     // the dot methods merge sorted lists (GB_MATRIX_WAIT_IF_JUMBLED on A and B, Source/GB_AxB_dot.c:78-87)
+    // (a sparse list is only ever merged with another sparse list: against a bitmap or full operand its entries are
+    // looked up by position, in any order, so a jumbled product -- tens of gigabytes -- is not copied and sorted
+    // just to be multiplied by a dense vector)
     gba_matrix Asorted, Bsorted;
-    if (!select_only && is_sparse(A) && A->jumbled) { GBA_OK(sorted_copy(A, &Asorted, ex.owned)); A = &Asorted; }
-    if (!select_only && is_sparse(B) && B->jumbled) { GBA_OK(sorted_copy(B, &Bsorted, ex.owned)); B = &Bsorted; }
+    if (!select_only && is_sparse(A) && A->jumbled && !is_dense_fmt(B)) { GBA_OK(sorted_copy(A, &Asorted, ex.owned)); A = &Asorted; }
+    if (!select_only && is_sparse(B) && B->jumbled && !is_dense_fmt(A)) { GBA_OK(sorted_copy(B, &Bsorted, ex.owned)); B = &Bsorted; }
     const bool C_iso = axb_iso(A, B, k.semiring, flipxy);
     if (C_iso && A->iso && as_if_full(A) && B->iso && as_if_full(B)) ex.rep.method = GBA_METHOD_ISO_FULL;
     if (dot4_control(C_iso, C_in, M, k.Mask_comp, k) && c.add != GBA_ANY &&

@@ -1008,6 +1008,13 @@ static constexpr int NUM_PANEL_SLOTS = 11264;                        // (any mul
 static constexpr int NUM_PANEL_TARGET = 3000;                         // distinct indices aimed at per panel (no boundaries known)
 static constexpr int NUM_PANEL_FIT = 8448;                            // entries between two recorded boundaries: three quarters of the slots
 static constexpr int SYM_WORDS_PER_THREAD = SYM_PANEL_WORDS / PANEL_THREADS;
+// The bitmap is stored with one word of padding after every thread's slice: slice t starts at word t * (SWPT + 1).
+// In the passes that count, list and clear the bitmap every thread walks its own slice; without the padding the
+// lanes of a wave are 32 words apart and fall on the same LDS banks (an 8-way conflict on every 16-byte access),
+// with it lane t reads bank t.
+static constexpr int SYM_SLICE_STRIDE = SYM_WORDS_PER_THREAD + 1;
+static constexpr int SYM_PANEL_LDS_WORDS = PANEL_THREADS * SYM_SLICE_STRIDE;
+static_assert(SYM_WORDS_PER_THREAD == 32, "the slice of word w is w >> 5");
 static constexpr int PANEL_PROBE_LIMIT = 48;
 static constexpr int64_t PANEL_INF = (int64_t)1 << 62;
 static constexpr int PANEL_SCRATCH_ARRAYS = 5;
@@ -1547,7 +1554,7 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
     __shared__ PanelSegs Q;
     __shared__ int64_t row;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int w = tid; w < SYM_PANEL_WORDS; w += PANEL_THREADS) bm[w] = 0;
+    for (int w = tid; w < SYM_PANEL_LDS_WORDS; w += PANEL_THREADS) bm[w] = 0;
     if (tid == 0) { Q.nseg = 0; Q.overflow = 0; }
 #ifdef GBA_PANEL_TICKS
     if (tid == 0) for (int q = 0; q < 8; q++) Q.tk[q] = 0;
@@ -1579,22 +1586,20 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                         if (!ok[u]) continue;
                         if constexpr (MASKED) { if (!mask_allows(M, i[u], j)) continue; }
                         const uint32_t o = (uint32_t)(i[u] - base);
-                        atomicOr(&bm[o >> 5], 1u << (o & 31));
+                        atomicOr(&bm[(o >> 5) + (o >> 10)], 1u << (o & 31));     // (word o >> 5, in slice o >> 10)
                     }
                 }, false);
-            // count in index order: each thread owns SYM_WORDS_PER_THREAD consecutive words, read once with 16-byte
-            // LDS loads (conflict-free at this stride); the packed sum carries the entries (low 21 bits: a panel has
-            // at most 2^20) and the non-empty words (above) of the slice
+            // count in index order: each thread owns SYM_WORDS_PER_THREAD consecutive words (its slice); the packed
+            // sum carries the entries (low 21 bits: a panel has at most 2^20) and the non-empty words (above)
             const int w0 = tid * SYM_WORDS_PER_THREAD;
-            uint4 *b4 = reinterpret_cast<uint4 *>(bm + w0);
+            uint32_t *mine_bm = bm + tid * SYM_SLICE_STRIDE;
             uint64_t both = 0;
-#pragma unroll
-            for (int q = 0; q < SYM_WORDS_PER_THREAD / 4; q++) {
-                const uint4 v = b4[q];
-                both += (uint64_t)(__builtin_popcount(v.x) + __builtin_popcount(v.y) + __builtin_popcount(v.z) + __builtin_popcount(v.w))
-                      + ((uint64_t)((v.x != 0u) + (v.y != 0u) + (v.z != 0u) + (v.w != 0u)) << 21);
+#pragma unroll 8
+            for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) {
+                const uint32_t x = mine_bm[q];
+                both += (uint64_t)__builtin_popcount(x) + ((uint64_t)(x != 0u) << 21);
             }
-            const int mine = (int)(both & 0x1fffffu), nzc = (int)(both >> 21);
+            const int mine = (int)(both & 0x1fffffu);
             uint64_t incl2 = both;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint64_t u = __shfl_up((unsigned long long)incl2, d, 64); if (lane >= d) incl2 += u; }
@@ -1608,46 +1613,37 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
             const int nzlo = (int)(excl2 >> 21);                // non-empty words of the panel before this thread's slice
             const int64_t lo = seen + (int64_t)(excl2 & 0x1fffffu);   // entries before this thread's slice
             const int64_t m = lo / NUM_PANEL_FIT + 1;       // the next multiple to be crossed
-            if (m * NUM_PANEL_FIT <= lo + mine) {
-                int r = (int)(m * NUM_PANEL_FIT - lo);      // the r-th set bit of the slice, 1-based
-                int nzb = 0;                                // non-empty words of the slice before the one that holds it
-                for (int q = 0; q < SYM_WORDS_PER_THREAD && r > 0; q++) {
-                    const uint32_t xq = bm[w0 + q];
-                    const int pcq = __builtin_popcount(xq);
-                    if (r <= pcq) {
-                        uint32_t y = xq;
-                        for (int z = 1; z < r; z++) y &= y - 1;
-                        jb[m - 1] = base + (int64_t)(w0 + q) * 32 + __builtin_ctz(y) + 1;
-                        if (jw) jw[m - 1] = wseen + nzlo + nzb;   // where that word stands in the vector's list of words
-                        r = 0;
-                    } else {
-                        r -= pcq;
-                        nzb += (xq != 0u) ? 1 : 0;
-                    }
-                }
-            }
-            // The pattern itself, for the numeric sweep that ranks instead of hashing: the non-empty words of the
-            // bitmap as (word number, bits) pairs in index order.  A thread's words follow those of the thread before,
-            // so the lanes of a wave write neighbouring places: one trip per word, whatever its bits, no staging.
-            if (pw) {
-                uint2 *out = pw + wseen + nzlo;
+            // second walk over the slice: the boundary that falls into it, if any; the pattern itself, for the numeric
+            // sweep that ranks instead of hashing -- the non-empty words as (word number, bits) pairs in index order,
+            // a thread's words behind those of the thread before, so the lanes of a wave write neighbouring places;
+            // and the slice is left clean (own slice only: no barrier needed)
+            if (mine) {
+                int r = (m * NUM_PANEL_FIT <= lo + mine) ? (int)(m * NUM_PANEL_FIT - lo) : 0;   // the r-th set bit of the slice, 1-based
+                int nzb = 0;                                // non-empty words of the slice so far
+                uint2 *out = pw ? pw + wseen + nzlo : nullptr;
                 const uint32_t wid0 = (uint32_t)(base >> 5) + (uint32_t)w0;
-                if (nzc) {
-#pragma unroll
-                    for (int q = 0; q < SYM_WORDS_PER_THREAD / 4; q++) {
-                        const uint4 v = b4[q];
-                        if (v.x) *out++ = make_uint2(wid0 + 4u * q, v.x);
-                        if (v.y) *out++ = make_uint2(wid0 + 4u * q + 1u, v.y);
-                        if (v.z) *out++ = make_uint2(wid0 + 4u * q + 2u, v.z);
-                        if (v.w) *out++ = make_uint2(wid0 + 4u * q + 3u, v.w);
+#pragma unroll 4
+                for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) {
+                    const uint32_t xq = mine_bm[q];
+                    if (xq == 0u) continue;
+                    mine_bm[q] = 0u;
+                    if (r > 0) {
+                        const int pcq = __builtin_popcount(xq);
+                        if (r <= pcq) {
+                            uint32_t y = xq;
+                            for (int z = 1; z < r; z++) y &= y - 1;
+                            jb[m - 1] = base + (int64_t)(w0 + q) * 32 + __builtin_ctz(y) + 1;
+                            if (jw) jw[m - 1] = wseen + nzlo + nzb;   // where that word stands in the vector's list of words
+                            r = 0;
+                        } else {
+                            r -= pcq;
+                        }
                     }
+                    if (out) out[nzb] = make_uint2(wid0 + (uint32_t)q, xq);
+                    nzb++;
                 }
-                wseen += nztotal;
             }
-            if (mine) {                                     // own slice only: no barrier needed
-#pragma unroll
-                for (int q = 0; q < SYM_WORDS_PER_THREAD / 4; q++) b4[q] = make_uint4(0u, 0u, 0u, 0u);
-            }
+            if (pw) wseen += nztotal;
             seen += total;
             const int more = Q.more;
             pc.swap();
@@ -2278,7 +2274,7 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
         GBA_OK(scratch.alloc((size_t)nblocks * PANEL_SCRATCH_ARRAYS * (size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
         GBA_OK(next.alloc(8));
         GBA_HIP(hipMemsetAsync(next.p, 0, 8, st));
-        const size_t lds = (size_t)SYM_PANEL_WORDS * 4;
+        const size_t lds = (size_t)SYM_PANEL_LDS_WORDS * 4;
         auto k = (P.M.kind == 0) ? sym_panel_kernel<false> : sym_panel_kernel<true>;
         GBA_OK(set_lds(k, lds));
         DevBuf order;
