@@ -61,7 +61,8 @@ def spmv(args):
         rep = fn()
         gbs = (bytes_spmv + extra_bytes) / (ms * 1e-3) / 1e9
         emit(case=label, method=g.Method.NAMES[rep.method], ms=round(ms, 4), wall_ms=round(wall, 4),
-             achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4), GFLOPs=round(2 * nnz / ms / 1e6, 1), **base)
+             achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4), GFLOPs=round(2 * nnz / ms / 1e6, 1),
+             w_i=int(rep.index_bytes) or 8, **base)
 
     run("y += A*x (accum PLUS, y full)", lambda: g.mxv(dy, None, PLUS, SR, dA, dx))
 

@@ -106,7 +106,7 @@ class gba_report(C.Structure):
                 ("bin_vectors", C.c_int64 * 4), ("bin_cnz", C.c_int64 * 4), ("bin_bnz", C.c_int64 * 4),
                 ("bin_madds", C.c_int64 * 4),
                 ("panels", C.c_int64), ("panels_redone", C.c_int64), ("cnz", C.c_int64),
-                ("typecast", C.c_int32), ("reserved", C.c_int32)]
+                ("typecast", C.c_int32), ("index_bytes", C.c_int32)]
 
 
 class gba_user_semiring(C.Structure):
@@ -195,7 +195,7 @@ class _Lib:
             "gba_pool_stats": (i32, [P(C.c_size_t), P(C.c_size_t)]),
             "gba_host_malloc": (vp, [C.c_size_t]), "gba_host_calloc": (vp, [C.c_size_t, C.c_size_t]),
             "gba_host_realloc": (vp, [vp, C.c_size_t]), "gba_host_free": (None, [vp]),
-            "gba_is_device_visible": (i32, [vp]),
+            "gba_is_device_visible": (i32, [vp]), "gba_matrix_forget": (i32, [M]),
             "gba_memcpy_h2d": (i32, [vp, vp, C.c_size_t]), "gba_memcpy_d2h": (i32, [vp, vp, C.c_size_t]),
             "gba_memset": (i32, [vp, C.c_int, C.c_size_t]), "gba_sync": (i32, []), "gba_stream": (vp, []),
             "gba_timer_start": (i32, []), "gba_timer_stop": (i32, [P(C.c_double)]),

@@ -188,11 +188,21 @@ dot_tile_rows_kernel(int64_t nvec, const int64_t *__restrict__ Ap, int64_t tile,
     }
 }
 
+// out[e] = (int32) in[e] for the entries Ap[0] .. Ap[nvec) of a sparse matrix (a view may start inside its arrays)
+__global__ void __launch_bounds__(256)
+narrow_indices_kernel(const int64_t *__restrict__ Ap, int64_t nvec, const int64_t *__restrict__ in, int32_t *__restrict__ out) {
+    const int64_t e0 = Ap[0], e1 = Ap[nvec];
+    int64_t e = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < e1; e += stride) out[e - e0] = (int32_t)in[e];          // (entry e of the view is out[e - Ap[0]])
+}
+
 static constexpr int DOT_SEG_SERIAL = 32;       // row segments longer than this are reduced by a whole wave
 
-template <class S, int MODE>
+// (IDX: the type the indices are read in -- int64_t as the caller holds them, or int32_t from the remembered copy)
+template <class S, int MODE, class IDX>
 __global__ void __launch_bounds__(DOT_TILE_THREADS)
-dot_tile_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+dot_tile_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const IDX *__restrict__ Ai,
                 const void *__restrict__ Ax_, bool A_iso, DenseView B, MaskViewD M,
                 typename S::z_t *__restrict__ Cx, int8_t *__restrict__ Cb, int64_t cvlen,
                 const int64_t *__restrict__ tile_row) {
@@ -208,6 +218,7 @@ dot_tile_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64
     const int64_t pN = Ap[nvecA];
     const int64_t start = Ap[0] + (int64_t)blockIdx.x * DOT_TILE;
     if (start >= pN) return;                                  // uniform
+    if (sizeof(IDX) == 4) Ai -= Ap[0];                        // the 32-bit copy holds the view's own entries only
     const int64_t end = (start + DOT_TILE < pN) ? start + DOT_TILE : pN;
     const int64_t r0 = tile_row[blockIdx.x];                  // row holding the first entry of the tile
     __shared__ int longq[DOT_TILE / DOT_SEG_SERIAL + 2];
@@ -226,7 +237,7 @@ dot_tile_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64
         int64_t k[DOT_TILE_ITEMS]; X av[DOT_TILE_ITEMS], bv[DOT_TILE_ITEMS];
 #pragma unroll
         for (int it = 0; it < DOT_TILE_ITEMS; it++)           // streamed once: keep the cache for B
-            k[it] = __builtin_nontemporal_load(&Ai[start + it * DOT_TILE_THREADS + tid]);
+            k[it] = (int64_t)__builtin_nontemporal_load(&Ai[start + it * DOT_TILE_THREADS + tid]);
 #pragma unroll
         for (int it = 0; it < DOT_TILE_ITEMS; it++)
             av[it] = apat ? X() : __builtin_nontemporal_load(&Ax[A_iso ? 0 : start + it * DOT_TILE_THREADS + tid]);
@@ -240,7 +251,7 @@ dot_tile_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const int64
             const int idx = it * DOT_TILE_THREADS + tid;
             const int64_t p = start + idx;
             if (p < end) {
-                const int64_t k = __builtin_nontemporal_load(&Ai[p]);
+                const int64_t k = (int64_t)__builtin_nontemporal_load(&Ai[p]);
                 const bool ok = plain || B.b[boff + k];
                 Z t = Z();
                 if (ok) t = sr.mult(((apat) ? X() : __builtin_nontemporal_load(&Ax[A_iso ? 0 : p])), load_x<X>(Bx, boff + k, B.iso, bpat), 0, k, j);
@@ -351,14 +362,48 @@ static gba_info dot_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask_c
                                            reinterpret_cast<Z *>(cx), cn, sr.identity());
                     }
                     const int64_t ntiles = ceil_div(A->nvals, DOT_TILE);
-                    GBA_OK(tile_rows.alloc((size_t)ntiles * 8));
                     int64_t rb = ceil_div(A->nvec, 256); if (rb > 8192) rb = 8192; if (rb < 1) rb = 1;
-                    hipLaunchKernelGGL(dot_tile_rows_kernel, dim3((unsigned)rb), dim3(256), 0, st, A->nvec, A->p,
-                                       (int64_t)DOT_TILE, tile_rows.as<int64_t>());
                     dim3 tgrid((unsigned)ntiles, (unsigned)cvdim);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(dot_tile_kernel<S, MODE>), tgrid, dim3(DOT_TILE_THREADS), 0, st, sr,
-                                       A->nvec, A->p, A->i, A->x, A->iso, Bv, mv, reinterpret_cast<Z *>(cx), cb, cvlen,
-                                       tile_rows.as<int64_t>());
+                    // A pattern seen before (an iteration multiplies by the same matrix again and again): the tile table
+                    // and a 32-bit copy of the indices are built once and kept; the kernel then streams 4-byte indices.
+                    PatternAux *aux = pattern_aux(A);
+                    const int32_t *i32 = nullptr;
+                    const int64_t *trow = nullptr;
+                    if (aux && aux->sightings >= 2) {
+                        if (!aux->tile_row[0] || aux->tile_size[0] != DOT_TILE) {
+                            if (aux->tile_row[0]) { gba_free(aux->tile_row[0]); aux->tile_row[0] = nullptr; }
+                            aux->tile_row[0] = reinterpret_cast<int64_t *>(gba_malloc((size_t)ntiles * 8));
+                            if (aux->tile_row[0]) {
+                                aux->tile_size[0] = DOT_TILE;
+                                hipLaunchKernelGGL(dot_tile_rows_kernel, dim3((unsigned)rb), dim3(256), 0, st, A->nvec, A->p,
+                                                   (int64_t)DOT_TILE, aux->tile_row[0]);
+                            }
+                        }
+                        trow = aux->tile_row[0];
+                        if (!aux->i32 && A->vlen < (int64_t)0x7fffffff) {
+                            aux->i32 = reinterpret_cast<int32_t *>(gba_malloc((size_t)A->nvals * 4));
+                            if (aux->i32) {
+                                int64_t nb = ceil_div(A->nvals, 1024); if (nb > 16384) nb = 16384;
+                                hipLaunchKernelGGL(narrow_indices_kernel, dim3((unsigned)nb), dim3(256), 0, st, A->p, A->nvec, A->i, aux->i32);
+                            }
+                        }
+                        i32 = aux->i32;
+                    }
+                    if (!trow) {
+                        GBA_OK(tile_rows.alloc((size_t)ntiles * 8));
+                        hipLaunchKernelGGL(dot_tile_rows_kernel, dim3((unsigned)rb), dim3(256), 0, st, A->nvec, A->p,
+                                           (int64_t)DOT_TILE, tile_rows.as<int64_t>());
+                        trow = tile_rows.as<int64_t>();
+                    }
+                    if (i32) {
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(dot_tile_kernel<S, MODE, int32_t>), tgrid, dim3(DOT_TILE_THREADS), 0, st, sr,
+                                           A->nvec, A->p, i32, A->x, A->iso, Bv, mv, reinterpret_cast<Z *>(cx), cb, cvlen, trow);
+                        if (rep) rep->index_bytes = 4;          // bytes per index the kernel streamed
+                    } else {
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(dot_tile_kernel<S, MODE, int64_t>), tgrid, dim3(DOT_TILE_THREADS), 0, st, sr,
+                                           A->nvec, A->p, A->i, A->x, A->iso, Bv, mv, reinterpret_cast<Z *>(cx), cb, cvlen, trow);
+                        if (rep) rep->index_bytes = 8;
+                    }
                 } else if (MODE == 1) {
                     GBA_HIP(hipMemsetAsync(cb, 0, (size_t)(cvlen * cvdim), st));
                 }

@@ -214,6 +214,24 @@ gba_info sorted_copy(const gba_matrix *X, gba_matrix *out, std::vector<void *> &
 
 // stage a host-resident view into device memory (PCIe); owned[] collects the
 // buffers to free afterwards
+// ---- what the library remembers about the PATTERN of sparse matrices it has multiplied by before -------------
+// The reference keeps such auxiliaries inside the matrix object (A->Y, the hashed hyperlist,
+// Source/Shared/GB_matrix.h:240-306: built on first use, dropped when the matrix changes).  Here the matrix is a
+// caller's view, so they are kept beside it, keyed by the addresses of p and i, nvals, nvec and vlen.  Only the
+// pattern is remembered (values may change freely).  An entry is dropped when one of its arrays is given back with
+// gba_free, by gba_matrix_forget, or when it is the least recently used of PATTERN_AUX_SLOTS.
+struct PatternAux {
+    const void *p = nullptr, *i = nullptr;
+    int64_t nvals = 0, nvec = 0, vlen = 0;
+    int32_t *i32 = nullptr;             // the indices in 32 bits (vlen < 2^31), or null
+    int64_t *tile_row[2] = {nullptr, nullptr};      // first vector of every tile of tile_size[k] entries, or null
+    int64_t tile_size[2] = {0, 0};
+    uint64_t sightings = 0, stamp = 0;
+};
+// the entry of A, created (empty) when absent; null when the cache is off (GBA_PATTERN_CACHE=0) or A does not qualify
+PatternAux *pattern_aux(const gba_matrix *A);
+void pattern_aux_forget_pointer(const void *ptr);       // called by gba_free
+
 // device view of a host operand.  GBA_MEM_HOST: copied.  GBA_MEM_HOST_VISIBLE (pinned memory mapped into the
 // device's address space): read in place when `in_place` (each entry is read about once), copied otherwise.
 gba_info stage_to_device(const gba_matrix *in, gba_matrix *out, std::vector<void *> &owned, bool in_place = false);

@@ -502,6 +502,46 @@ public:
 };
 static Pool &pool() { static Pool p; return p; }
 
+// ------------------------------------------------------ pattern auxiliaries --
+static constexpr int PATTERN_AUX_SLOTS = 8;
+static std::mutex g_aux_mu;
+static PatternAux g_aux[PATTERN_AUX_SLOTS];
+static uint64_t g_aux_clock = 0;
+
+static void aux_drop_locked(PatternAux &e) {
+    void *bufs[3] = {e.i32, e.tile_row[0], e.tile_row[1]};
+    e = PatternAux();
+    for (void *b : bufs) if (b) pool().give(b);         // (straight to the pool: gba_free would come back here)
+}
+
+PatternAux *pattern_aux(const gba_matrix *A) {
+    static const bool on = [] { const char *e = getenv("GBA_PATTERN_CACHE"); return !(e && atoi(e) == 0); }();
+    if (!on || !A || A->mem != GBA_MEM_DEVICE || !A->p || !A->i || A->nzombies || A->nvals < (int64_t)1 << 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    PatternAux *lru = &g_aux[0];
+    for (PatternAux &e : g_aux) {
+        if (e.p == A->p && e.i == A->i && e.nvals == A->nvals && e.nvec == A->nvec && e.vlen == A->vlen) {
+            e.sightings++; e.stamp = ++g_aux_clock;
+            return &e;
+        }
+        if (e.stamp < lru->stamp) lru = &e;
+    }
+    aux_drop_locked(*lru);
+    lru->p = A->p; lru->i = A->i; lru->nvals = A->nvals; lru->nvec = A->nvec; lru->vlen = A->vlen;
+    lru->sightings = 1; lru->stamp = ++g_aux_clock;
+    return lru;
+}
+
+void pattern_aux_forget_pointer(const void *ptr) {
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    for (PatternAux &e : g_aux) if (e.p && (e.p == ptr || e.i == ptr)) aux_drop_locked(e);
+}
+
+static void pattern_aux_clear() {
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    for (PatternAux &e : g_aux) aux_drop_locked(e);
+}
+
 }  // namespace gba
 
 // ============================================================== C ABI ======
@@ -540,6 +580,7 @@ gba_info gba_finalize(void) {
     Context &c = ctx();
     if (!c.inited) return GBA_SUCCESS;
     hipStreamSynchronize(c.stream);
+    pattern_aux_clear();
     pool().release_all();
     jit_unload_all();
     hipEventDestroy(c.ev0);
@@ -558,7 +599,7 @@ void *gba_malloc(size_t nbytes) {
     if (!ctx().inited) { set_error("gba_malloc before gba_init"); return nullptr; }
     return pool().take(nbytes ? nbytes : 1);
 }
-void gba_free(void *p) { if (p) pool().give(p); }
+void gba_free(void *p) { if (p) { pattern_aux_forget_pointer(p); pool().give(p); } }
 gba_info gba_pool_release(void) { pool().release_all(); return GBA_SUCCESS; }
 gba_info gba_pool_set_limit(size_t nbytes) { pool().set_limit(nbytes); return GBA_SUCCESS; }
 gba_info gba_pool_stats(size_t *cached_bytes, size_t *live_bytes) {
@@ -669,6 +710,13 @@ void gba_matrix_free_content(gba_matrix *A) {
     }
     A->p = A->h = A->i = nullptr; A->x = nullptr; A->b = nullptr;
     A->nvals = 0; A->nzombies = 0;
+}
+
+gba_info gba_matrix_forget(const gba_matrix *A) {
+    if (!A) return GBA_SUCCESS;
+    if (A->p) pattern_aux_forget_pointer(A->p);
+    if (A->i) pattern_aux_forget_pointer(A->i);
+    return GBA_SUCCESS;
 }
 
 gba_info gba_cumsum(int64_t *count_dev, int64_t n) {

@@ -180,7 +180,7 @@ typedef struct gba_report {
     int64_t panels_redone;  /* half width after a table overflow                                      */
     int64_t cnz;            /* entries produced (saxpy3, dot3) */
     int32_t typecast;       /* bit 0: A's values were cast to the multiplier's type, bit 1: B's, bit 2: T to C's type */
-    int32_t reserved;
+    int32_t index_bytes;    /* bytes per index the entry-tiled SpMV kernel streamed: 8, or 4 from the remembered copy; 0 otherwise */
 } gba_report;
 
 /* ------------------------------------------------------ library + memory -- */
@@ -224,6 +224,14 @@ void    *gba_stream(void);                 /* hipStream_t used by every kernel o
 /* HIP-event stopwatch on that stream: device time between the two calls, in ms */
 gba_info gba_timer_start(void);
 gba_info gba_timer_stop(double *ms);
+
+/* The library remembers auxiliaries of the PATTERN of the last few large sparse matrices it multiplied by (a 32-bit copy
+ * of the indices, the tile tables of the entry-tiled SpMV kernels), as the reference keeps A->Y with its matrix
+ * (Source/Shared/GB_matrix.h:240-306).  They are built when a pattern is seen for the second time and are keyed by
+ * the addresses of p and i, nvals, nvec and vlen; values are never remembered.  Arrays from gba_malloc are forgotten
+ * when they are freed.  A caller that REWRITES p or i of its own memory in place calls gba_matrix_forget (A) first.
+ * GBA_PATTERN_CACHE=0 turns the memory off. */
+gba_info gba_matrix_forget(const gba_matrix *A);
 
 /* Free the arrays a call allocated inside *A (p, h, i, x, b) and clear them.
  * GB_phybix_free analogue (Source/GB_phybix_free.c). */
