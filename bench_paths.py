@@ -248,13 +248,39 @@ def complex_spgemm(args):
          achieved=round(alg / (best * 1e-3) / 1e9, 1), unit="GB/s", peak=HBM_PEAK_GBS)
 
 
+def launch_ranks(gpus):
+    """`--gpus N` with N > 1 from a plain `python bench_paths.py`: start N ranks (one process per GPU, RCCL) and pass
+    their exit code on.  Nothing has touched the GPU yet: the ranks are children, not a replacement of this process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["spmv", "tricount", "bfs", "sssp", "complex"])
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--type", choices=["fp32", "fp64"], default="fp32", help="spmv value type")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU); above 1, or with GBA_BENCH_FORCE_DIST=1, the "
+                    "row-block programs of bench_paths_dist.py run instead of the one-GPU measurements")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
+    if a.gpus > 1 or os.environ.get("GBA_BENCH_FORCE_DIST"):
+        import bench_paths_dist
+        if a.what not in bench_paths_dist.PROGRAMS:
+            sys.exit(f"bench_paths.py: no sharded program for '{a.what}'")
+        _, rec = bench_paths_dist.run(a.what, a)
+        if rec is not None:
+            emit(**rec)
+        sys.exit(0)
     import graphblas_amd as g
     g.init(0)
     {"spmv": spmv, "tricount": tricount, "bfs": bfs, "sssp": sssp, "complex": complex_spgemm}[a.what](a)

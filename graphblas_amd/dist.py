@@ -60,13 +60,38 @@ def _all_gather_padded(dist, torch, send, pad, world):
     return flat
 
 
+def all_gather_in_place(dist, torch, mine, out, offs, counts, rank):
+    """All-gather of pieces of unequal length straight into their places: out[offs[r] : offs[r] + counts[r]]
+    receives the piece of rank r, `mine` is this rank's.  Nothing is padded and nothing is copied afterwards:
+    the slices of `out` are the receive buffers.  RCCL takes the list of unequal slices as it is (it moves each
+    piece as a broadcast inside one group); gloo wants equal shares, so there every piece is one broadcast, staged
+    through the host for device tensors."""
+    world = len(counts)
+    pieces = [out[offs[r]: offs[r] + counts[r]] for r in range(world)]
+    if dist.get_backend() != "gloo":
+        dist.all_gather(pieces, mine)
+        return
+    for r in range(world):
+        if counts[r] == 0:
+            continue
+        if out.is_cuda:
+            host = mine.cpu() if r == rank else torch.empty(counts[r], dtype=out.dtype)
+            dist.broadcast(host, src=r)
+            pieces[r].copy_(host)
+        else:
+            if r == rank:
+                pieces[r].copy_(mine)
+            dist.broadcast(pieces[r], src=r)
+
+
 class RowBlockExchange:
     """All-gather of the (i, x) arrays of a matrix distributed by row blocks.
 
     part[r]..part[r+1] are the rows of rank r and Ap the (replicated) row pointers, so entry
-    ranges are known everywhere and only indices and values travel: one all_gather_into_tensor per
-    array on a flat buffer (blocks padded to the longest one, the collective wants equal shares),
-    then one device copy per block into its place."""
+    ranges are known everywhere and only indices and values travel: one all-gather per array, every
+    block received at its own length straight into its place in the full array (flop-balanced blocks of a
+    power-law matrix hold unequal numbers of entries; padding them to the longest would move
+    world * max instead of the sum)."""
 
     def __init__(self, dist, torch, Ap, part, rank, device, idx_dtype, val_dtype, collective=None):
         self.dist, self.torch = dist, torch
@@ -76,47 +101,37 @@ class RowBlockExchange:
         self.collective = (self.world > 1) if collective is None else bool(collective)
         self.offs = [int(Ap[part[r]]) for r in range(self.world)]
         self.counts = [int(Ap[part[r + 1]] - Ap[part[r]]) for r in range(self.world)]
-        self.pad = max(max(self.counts), 1) if self.collective else 0
-        if self.collective:
-            self.si = torch.zeros(self.pad, dtype=idx_dtype, device=device)
-            self.sx = torch.zeros(self.pad, dtype=val_dtype, device=device)
+        self.moved = sum(self.counts)                       # entries a gather moves; padded it was world * max
+        self.padded = self.world * max(max(self.counts), 1)
 
     def gather(self, my_i, my_x, out_i, out_x):
         """my_i/my_x: this rank's entries; out_i/out_x: full-length arrays to fill."""
         if not self.collective:
             out_i.copy_(my_i); out_x.copy_(my_x)
             return
-        c = self.counts[self.rank]
-        self.si[:c].copy_(my_i); self.sx[:c].copy_(my_x)
-        for send, out in ((self.si, out_i), (self.sx, out_x)):
-            flat = _all_gather_padded(self.dist, self.torch, send, self.pad, self.world)
-            for r in range(self.world):
-                o, n = self.offs[r], self.counts[r]
-                out[o: o + n].copy_(flat[r * self.pad: r * self.pad + n])
+        for mine, out in ((my_i, out_i), (my_x, out_x)):
+            all_gather_in_place(self.dist, self.torch, mine, out, self.offs, self.counts, self.rank)
 
 
 class VectorBlockExchange:
     """A dense vector distributed by the same row blocks: y(I) is computed by the rank that owns rows I
-    (y(I) = A(I,:) x needs all of x), and the blocks are all-gathered into the full vector that the next
-    product reads -- the exchange of a PageRank-shaped iteration x <- A x (GrB_mxv, Source/GrB_mxv.c:57-66)."""
+    (y(I) = A(I,:) x needs all of x), and the blocks are all-gathered, each at its own length and straight into
+    its place, into the full vector that the next product reads -- the exchange of a PageRank-shaped iteration
+    x <- A x (GrB_mxv, Source/GrB_mxv.c:57-66)."""
 
-    def __init__(self, dist, torch, part, rank, device, dtype):
+    def __init__(self, dist, torch, part, rank, device, dtype, collective=None):
         self.dist, self.torch = dist, torch
         self.world, self.rank = len(part) - 1, rank
+        self.collective = (self.world > 1) if collective is None else bool(collective)
         self.part = [int(v) for v in part]
         self.counts = [self.part[r + 1] - self.part[r] for r in range(self.world)]
-        self.pad = max(max(self.counts), 1)
-        self.send = torch.zeros(self.pad, dtype=dtype, device=device) if self.world > 1 else None
 
     def gather(self, my_block, out):
         """my_block: this rank's entries y(I); out: the full-length vector to fill."""
-        if self.world == 1:
+        if not self.collective:
             out.copy_(my_block)
             return
-        self.send[: self.counts[self.rank]].copy_(my_block)
-        flat = _all_gather_padded(self.dist, self.torch, self.send, self.pad, self.world)
-        for r in range(self.world):
-            out[self.part[r]: self.part[r + 1]].copy_(flat[r * self.pad: r * self.pad + self.counts[r]])
+        all_gather_in_place(self.dist, self.torch, my_block, out, self.part[:-1], self.counts, self.rank)
 
 
 class FrontierExchange:
@@ -131,35 +146,37 @@ class FrontierExchange:
     with MIN (distances) or as a bitmap reduced with MAX (presence).  No reduction of w itself is needed:
     the row blocks are disjoint."""
 
-    def __init__(self, dist, torch, rank, world, device):
+    def __init__(self, dist, torch, rank, world, device, collective=None):
         self.dist, self.torch, self.rank, self.world, self.device = dist, torch, rank, world, device
+        self.collective = (world > 1) if collective is None else bool(collective)
 
     def sparse(self, my_idx, my_val):
         """my_idx: global indices of the entries this rank found (ascending), my_val their values.
         Returns the concatenation over ranks, in rank order (= ascending index order for row blocks)."""
         torch = self.torch
-        if self.world == 1:
+        if not self.collective:
             return my_idx, my_val
         cnt = torch.tensor([my_idx.numel()], dtype=torch.int64, device=self.device)
         counts = _all_gather_padded(self.dist, torch, cnt, 1, self.world).cpu().tolist()
-        pad = max(max(counts), 1)
+        offs = [0]
+        for c in counts[:-1]:
+            offs.append(offs[-1] + c)
         out = []
         for mine in (my_idx, my_val):
-            send = torch.zeros(pad, dtype=mine.dtype, device=self.device)
-            send[: mine.numel()].copy_(mine)
-            flat = _all_gather_padded(self.dist, torch, send, pad, self.world)
-            out.append(torch.cat([flat[r * pad: r * pad + counts[r]] for r in range(self.world)]))
+            whole = torch.empty(sum(counts), dtype=mine.dtype, device=self.device)
+            all_gather_in_place(self.dist, torch, mine, whole, offs, counts, self.rank)
+            out.append(whole)
         return out[0], out[1]
 
     def dense_min(self, d):
         """d: a full-length vector that holds this rank's block and the monoid identity (+inf) elsewhere."""
-        if self.world > 1:
+        if self.collective:
             self._all_reduce(d, self.dist.ReduceOp.MIN)
         return d
 
     def dense_or(self, b):
         """b: a full-length int8 bitmap that is zero outside this rank's block."""
-        if self.world > 1:
+        if self.collective:
             self._all_reduce(b, self.dist.ReduceOp.MAX)
         return b
 
@@ -177,12 +194,13 @@ class ScalarReduce:
     cut into row blocks, every rank multiplies C(I,:)<L(I,:)> = L(I,:)*L' against the whole of L (replicated, or
     gathered from the blocks with RowBlockExchange) and only the per-rank sums of C travel."""
 
-    def __init__(self, dist, torch, world, device):
+    def __init__(self, dist, torch, world, device, collective=None):
         self.dist, self.torch, self.world, self.device = dist, torch, world, device
+        self.collective = (world > 1) if collective is None else bool(collective)
 
     def sum_int64(self, value):
-        t = self.torch.tensor([int(value)], dtype=self.torch.int64,
-                              device=self.device if self.world > 1 and self.dist.get_backend() == "nccl" else "cpu")
-        if self.world > 1:
+        on_device = self.collective and self.dist.get_backend() == "nccl"
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device=self.device if on_device else "cpu")
+        if self.collective:
             self.dist.all_reduce(t)
         return int(t.item())
