@@ -69,12 +69,16 @@ def all_gather_in_place(dist, torch, mine, out, offs, counts, rank):
     world = len(counts)
     pieces = [out[offs[r]: offs[r] + counts[r]] for r in range(world)]
     if dist.get_backend() != "gloo":
-        dist.all_gather(pieces, mine)
-        return
+        try:
+            dist.all_gather(pieces, mine)
+            return
+        except (RuntimeError, ValueError, TypeError):       # a build that refuses unequal pieces: one broadcast each
+            pass
+    staged = dist.get_backend() == "gloo" and out.is_cuda
     for r in range(world):
         if counts[r] == 0:
             continue
-        if out.is_cuda:
+        if staged:
             host = mine.cpu() if r == rank else torch.empty(counts[r], dtype=out.dtype)
             dist.broadcast(host, src=r)
             pieces[r].copy_(host)
