@@ -616,7 +616,7 @@ bin_scatter_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const in
                    const void *__restrict__ Ax_, bool A_iso, DenseView B, int64_t j,
                    const int64_t *__restrict__ tile_row, int shift, int nb, int64_t nwg,
                    const int64_t *__restrict__ table, uint16_t *__restrict__ pair_idx,
-                   typename S::z_t *__restrict__ pair_val) {
+                   typename S::z_t *__restrict__ pair_val, const int32_t *__restrict__ narrow) {
     using X = typename S::x_t; using Z = typename S::z_t;
     constexpr int BIN_TILE = BIN_THREADS * BIN_ITEMS;
     constexpr int NLONG = BIN_TILE / DOT_SEG_SERIAL + 2, NGB = BIN_MAX / BIN_THREADS;
@@ -659,7 +659,9 @@ bin_scatter_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const in
     __syncthreads();
     // indices are below 2^31 here: only their low words are loaded (a load whose upper half is dead makes the
     // compiler reuse that register at once, and the reuse then has to wait for the load)
-    const int *Ai_lo = reinterpret_cast<const int *>(Ai);
+    // (`narrow`: the 32-bit copy of the indices kept with a pattern seen before, entry e at narrow[e - Ap[0]])
+    const int *Ai_lo = narrow ? narrow - p0 : reinterpret_cast<const int *>(Ai);
+    const int istride = narrow ? 1 : 2;
     const int64_t isomask = A_iso ? 0 : -1;                   // an iso A reads Ax[0] through the same vector loads
     auto issue = [&](int64_t t, int64_t tr0, int (&c)[BIN_ITEMS], X (&a)[BIN_ITEMS], int64_t &a0, int64_t &a1, X &xv) {
         const int64_t st = p0 + t * BIN_TILE;
@@ -668,7 +670,7 @@ bin_scatter_kernel(S sr, int64_t nvecA, const int64_t *__restrict__ Ap, const in
 #pragma unroll
         for (int it = 0; it < BIN_ITEMS; it++) {
             const int64_t p = st + it * BIN_THREADS + tid;
-            c[it] = __builtin_nontemporal_load(&Ai_lo[2 * (p < pN ? p : pN - 1)]);
+            c[it] = __builtin_nontemporal_load(&Ai_lo[istride * (p < pN ? p : pN - 1)]);
         }
         if (!apat) {
 #pragma unroll
@@ -891,7 +893,7 @@ bin_combine_kernel(S sr, int shift, int64_t cvlen, const int *__restrict__ chunk
 // C(:,j) += A * B(:,j) for every j, C full of the monoid's type, B full; false when the shape does not fit
 template <class S>
 static gba_info saxpy4_binned(S sr, const gba_matrix *A, const DenseView &Bv, int64_t cvlen, int64_t cvdim,
-                              typename S::z_t *cx, hipStream_t st, bool *done) {
+                              typename S::z_t *cx, hipStream_t st, bool *done, gba_report *rep) {
     using Z = typename S::z_t;
     *done = false;
     constexpr int shift = bin_shift<Z>::v, ITEMS = bin_items<S>::v, BIN_TILE = BIN_THREADS * ITEMS;
@@ -901,21 +903,57 @@ static gba_info saxpy4_binned(S sr, const gba_matrix *A, const DenseView &Bv, in
     const int nb = (int)nb64;
     const int64_t nwg = ceil_div(nnz, BIN_TILE), ncell = (int64_t)nb * nwg;
     const int64_t maxchunks = ceil_div(nnz, BIN_CHUNK) + nb;
-    DevBuf table, tile_rows, chunk_base, pidx, pval, parked;
-    GBA_OK(table.alloc((size_t)(ncell + 1) * 8));
-    GBA_OK(tile_rows.alloc((size_t)nwg * 8));
-    GBA_OK(chunk_base.alloc((size_t)(nb + 1) * 4));
+    DevBuf table_buf, tile_rows_buf, chunk_buf, pidx, pval, parked;
     GBA_OK(pidx.alloc((size_t)nnz * 2));
     GBA_OK(pval.alloc((size_t)nnz * sizeof(Z)));
     GBA_OK(parked.alloc((size_t)maxchunks * sizeof(Z) << shift));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_count_kernel<ITEMS>), dim3((unsigned)ceil_div(nwg, BIN_COUNT_TILES)), dim3(BIN_THREADS),
-                       (size_t)nb * 4 * BIN_COUNT_TILES, st, A->nvec, A->p, A->i,
-                       shift, nb, nwg, table.as<int64_t>());
-    GBA_OK(dev_cumsum_i64(table.as<int64_t>(), ncell, st));
-    int64_t rb = ceil_div(A->nvec, 256); if (rb > 8192) rb = 8192; if (rb < 1) rb = 1;
-    hipLaunchKernelGGL(dot_tile_rows_kernel, dim3((unsigned)rb), dim3(256), 0, st, A->nvec, A->p, (int64_t)BIN_TILE,
-                       tile_rows.as<int64_t>());
-    hipLaunchKernelGGL(bin_chunks_kernel, dim3(1), dim3(256), 0, st, nb, nwg, table.as<int64_t>(), chunk_base.as<int>());
+    // the plan (bin offsets of every tile, first vector of every tile, chunks per bin) depends on the pattern of A
+    // only: from the second product with the same A on it is kept with the pattern and not computed again
+    int64_t *table = nullptr, *tile_rows = nullptr; int *chunk_base = nullptr;
+    const int32_t *narrow = nullptr;
+    PatternAux *aux = pattern_aux(A);
+    bool planned = false;
+    if (aux && aux->sightings >= 2) {
+        if (aux->bin_table && (aux->bin_shift != shift || aux->bin_tile != BIN_TILE || aux->bin_cvlen != cvlen)) {
+            gba_free(aux->bin_table); gba_free(aux->bin_tile_rows); gba_free(aux->bin_chunks);
+            aux->bin_table = aux->bin_tile_rows = nullptr; aux->bin_chunks = nullptr;
+        }
+        planned = aux->bin_table != nullptr;
+        if (!planned) {
+            aux->bin_table = reinterpret_cast<int64_t *>(gba_malloc((size_t)(ncell + 1) * 8));
+            aux->bin_tile_rows = reinterpret_cast<int64_t *>(gba_malloc((size_t)nwg * 8));
+            aux->bin_chunks = reinterpret_cast<int *>(gba_malloc((size_t)(nb + 1) * 4));
+            if (!aux->bin_table || !aux->bin_tile_rows || !aux->bin_chunks) {
+                gba_free(aux->bin_table); gba_free(aux->bin_tile_rows); gba_free(aux->bin_chunks);
+                aux->bin_table = aux->bin_tile_rows = nullptr; aux->bin_chunks = nullptr;
+            } else {
+                aux->bin_shift = shift; aux->bin_tile = BIN_TILE; aux->bin_cvlen = cvlen;
+            }
+        }
+        table = aux->bin_table; tile_rows = aux->bin_tile_rows; chunk_base = aux->bin_chunks;
+        if (!aux->i32 && A->vlen < (int64_t)0x7fffffff) {
+            aux->i32 = reinterpret_cast<int32_t *>(gba_malloc((size_t)A->nvals * 4));
+            if (aux->i32) {
+                int64_t nbk = ceil_div(A->nvals, 1024); if (nbk > 16384) nbk = 16384;
+                hipLaunchKernelGGL(narrow_indices_kernel, dim3((unsigned)nbk), dim3(256), 0, st, A->p, A->nvec, A->i, aux->i32);
+            }
+        }
+        narrow = aux->i32;
+    }
+    if (!table) {
+        GBA_OK(table_buf.alloc((size_t)(ncell + 1) * 8));
+        GBA_OK(tile_rows_buf.alloc((size_t)nwg * 8));
+        GBA_OK(chunk_buf.alloc((size_t)(nb + 1) * 4));
+        table = table_buf.as<int64_t>(); tile_rows = tile_rows_buf.as<int64_t>(); chunk_base = chunk_buf.as<int>();
+    }
+    if (!planned) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_count_kernel<ITEMS>), dim3((unsigned)ceil_div(nwg, BIN_COUNT_TILES)), dim3(BIN_THREADS),
+                           (size_t)nb * 4 * BIN_COUNT_TILES, st, A->nvec, A->p, A->i, shift, nb, nwg, table);
+        GBA_OK(dev_cumsum_i64(table, ncell, st));
+        int64_t rb = ceil_div(A->nvec, 256); if (rb > 8192) rb = 8192; if (rb < 1) rb = 1;
+        hipLaunchKernelGGL(dot_tile_rows_kernel, dim3((unsigned)rb), dim3(256), 0, st, A->nvec, A->p, (int64_t)BIN_TILE, tile_rows);
+        hipLaunchKernelGGL(bin_chunks_kernel, dim3(1), dim3(256), 0, st, nb, nwg, table, chunk_base);
+    }
     // as many bin_scatter workgroups as stay resident together, each walking tiles (at most BIN_WALK of them)
     int per_cu = 1;
     GBA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bin_scatter_kernel<S, ITEMS>, BIN_THREADS, (size_t)nb * 8));
@@ -925,15 +963,15 @@ static gba_info saxpy4_binned(S sr, const gba_matrix *A, const DenseView &Bv, in
     if (sgrid < need) sgrid = need;
     for (int64_t j = 0; j < cvdim; j++) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_scatter_kernel<S, ITEMS>), dim3((unsigned)sgrid), dim3(BIN_THREADS), (size_t)nb * 8, st,
-                           sr, A->nvec, A->p, A->i, A->x, A->iso, Bv, j, tile_rows.as<int64_t>(), shift, nb, nwg,
-                           table.as<int64_t>(), pidx.as<uint16_t>(), pval.as<Z>());
+                           sr, A->nvec, A->p, A->i, A->x, A->iso, Bv, j, tile_rows, shift, nb, nwg,
+                           table, pidx.as<uint16_t>(), pval.as<Z>(), narrow);
         GBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_reduce_kernel<S>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(typename bin_panel<Z>::type) << shift)));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_reduce_kernel<S>), dim3((unsigned)maxchunks), dim3(BIN_REDUCE_THREADS), sizeof(typename bin_panel<Z>::type) << shift, st,
-                           sr, shift, nb, nwg, table.as<int64_t>(), chunk_base.as<int>(), pidx.as<uint16_t>(), pval.as<Z>(),
+                           sr, shift, nb, nwg, table, chunk_base, pidx.as<uint16_t>(), pval.as<Z>(),
                            cx + j * cvlen, cvlen, parked.as<Z>());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(bin_combine_kernel<S>), dim3(grid_for(cvlen)), dim3(256), 0, st, sr, shift, cvlen,
-                           chunk_base.as<int>(), parked.as<Z>(), cx + j * cvlen);
+                           chunk_base, parked.as<Z>(), cx + j * cvlen);
     }
     GBA_HIP(hipGetLastError());
     GBA_HIP(hipStreamSynchronize(st));                        // the buffers above go back to the pool on return
@@ -947,6 +985,7 @@ static gba_info saxpy4_binned(S sr, const gba_matrix *A, const DenseView &Bv, in
                 (double)t[5] / nwg, (double)t[6] / nwg, (long)nwg);
     }
 #endif
+    if (rep) rep->index_bytes = narrow ? 4 : 8;               // bytes per index the scatter fetched
     *done = true;
     return GBA_SUCCESS;
 }
@@ -1082,7 +1121,7 @@ static gba_info saxpy_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask
             if (MODE == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(fill_kernel<ACC>), dim3(grid_for(cn)), dim3(256), 0, st, acc, cn, (ACC)sr.identity());
             if constexpr (MODE == 0 && dot_tile_ok<S>::v) {
                 bool done = false;
-                GBA_OK(saxpy4_binned<S>(sr, A, Bv, cvlen, cvdim, cx, st, &done));
+                GBA_OK(saxpy4_binned<S>(sr, A, Bv, cvlen, cvdim, cx, st, &done, rep));
                 if (done) return GBA_SUCCESS;
             }
             DevBuf tile_rows;

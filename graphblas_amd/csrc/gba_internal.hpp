@@ -226,6 +226,12 @@ struct PatternAux {
     int32_t *i32 = nullptr;             // the indices in 32 bits (vlen < 2^31), or null
     int64_t *tile_row[2] = {nullptr, nullptr};      // first vector of every tile of tile_size[k] entries, or null
     int64_t tile_size[2] = {0, 0};
+    // the plan of the destination-binned scatter (saxpy4 with a sparse A and full B, C): where every tile's pairs
+    // go per bin, the first vector of every tile, the chunks of every bin.  Depends on the pattern only.
+    int64_t *bin_table = nullptr, *bin_tile_rows = nullptr;
+    int *bin_chunks = nullptr;
+    int bin_shift = 0;
+    int64_t bin_tile = 0, bin_cvlen = 0;
     uint64_t sightings = 0, stamp = 0;
 };
 // the entry of A, created (empty) when absent; null when the cache is off (GBA_PATTERN_CACHE=0) or A does not qualify

@@ -509,7 +509,7 @@ static PatternAux g_aux[PATTERN_AUX_SLOTS];
 static uint64_t g_aux_clock = 0;
 
 static void aux_drop_locked(PatternAux &e) {
-    void *bufs[3] = {e.i32, e.tile_row[0], e.tile_row[1]};
+    void *bufs[6] = {e.i32, e.tile_row[0], e.tile_row[1], e.bin_table, e.bin_tile_rows, e.bin_chunks};
     e = PatternAux();
     for (void *b : bufs) if (b) pool().give(b);         // (straight to the pool: gba_free would come back here)
 }
