@@ -399,6 +399,11 @@ def matrix_wait(A):
     lib.check(lib.gba_matrix_wait(A.ref()))
 
 
+def matrix_forget(A):
+    """Drop what the library remembers about the pattern of A (to be called before p or i of A are rewritten in place)."""
+    lib.check(lib.gba_matrix_forget(A.ref()))
+
+
 def transpose(A):
     out = _new_result(A.view.type)
     lib.check(lib.gba_transpose(out.ref(), A.ref()))
