@@ -266,6 +266,7 @@ def main():
         # secondary model: every product streams its A entry (no reuse of A out of cache)
         k_stream = ((stats["bin_bnz"][k] + stats["bin_madds"][k] + stats["bin_cnz"][k]) * (w_i + w_v)) / launches
         streamed = k_stream / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        counters = measured_counters(f"RMAT-{args.scale} ef={args.edge_factor}", names[k])
         out = {
             "metric": "SpGEMM semiring GFLOP/s, RMAT C=A*A PLUS_TIMES_FP64",
             "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -280,11 +281,11 @@ def main():
             "numeric_bin_vectors_rank0": [int(x) // max(args.steps, 1) for x in stats["bins"]],
             "roofline": {"bound": "hbm", "kernel": names[k], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         **measured_counters(f"RMAT-{args.scale} ef={args.edge_factor}", names[k]),
-                         # what holds the kernel below the HBM line (in-kernel stopwatch build and instruction counters)
-                         "limiter": "per-panel chain of dependent phases (search 20 %, run queue 5 %, windows of products "
-                                    "55 %, emit 10 %) in one 1024-thread workgroup per CU; 148 VALU + 85 scalar "
-                                    "instructions per 64 products",
+                         **{kk: vv for kk, vv in counters.items() if not kk.startswith("insts_") and not kk.startswith("wave_")},
+                         # what holds the kernel below the HBM line, worded from this run's phases and panel counts and
+                         # from the committed counter passes of the same workload
+                         "limiter": limiter_text(names[k], k_ms, stats["bin_madds"][k] / launches,
+                                                 stats.get("panels", 0) / launches, counters),
                          "avg_launch_ms": round(float(k_ms), 3), "algorithmic_bytes_per_launch": int(k_bytes),
                          "streaming_model_GBps": round(streamed, 2),
                          "kernel_multiply_adds_per_launch": int(stats["bin_madds"][k] // launches)},
@@ -372,13 +373,34 @@ def measured_counters(workload, kernel):
             rec = json.load(f).get(workload)
         if rec and rec["kernel"].split("<")[0] == kernel.split("<")[0]:
             out["traffic"] = int(rec["traffic"])
-            for key in ("lds_bank_conflict_frac", "waves_per_busy_cu"):
+            for key in ("lds_bank_conflict_frac", "waves_per_busy_cu", "insts_valu", "insts_salu", "insts_lds",
+                        "wave_issue_frac", "wave_wait_frac"):
                 if key in rec:
                     out[key] = rec[key]
             out["counters_from"] = "profiles/ " + str(rec.get("round", ""))
     except (OSError, ValueError, KeyError):
         pass
     return out
+
+
+def limiter_text(kernel, ms, madds, panels, counters):
+    """One sentence on what bounds the dominant kernel, put together from numbers: this run's time, multiply-adds and
+    LDS panels per launch, and (when the committed counter passes cover this workload) the instructions issued per
+    64 products and the share of cycles in which the resident waves issue or wait."""
+    if ms <= 0 or madds <= 0:
+        return None
+    parts = [f"{kernel}: {ms:.0f} ms per launch for {madds:.3g} multiply-adds = {ms * 1e9 / madds:.1f} ps per product"]
+    if kernel == "num_panel_kernel" and panels > 0:
+        parts.append(f"{panels:.0f} LDS panels per launch, each a chain of dependent phases (cursor search, run queue, windows "
+                     f"of products, emit) on one 1024-thread workgroup per CU: {ms * 1e3 / panels * 256:.1f} us of CU time and "
+                     f"{madds / panels:.0f} products per panel")
+    if counters.get("insts_valu"):
+        per64 = lambda key: counters.get(key, 0) * 64.0 / madds
+        parts.append(f"issue-bound, not HBM-bound: {per64('insts_valu'):.0f} vector + {per64('insts_salu'):.0f} scalar + "
+                     f"{per64('insts_lds'):.0f} LDS instructions per 64 products; the resident waves issue in "
+                     f"{100 * counters.get('wave_issue_frac', 0):.0f} % and wait in {100 * counters.get('wave_wait_frac', 0):.0f} % "
+                     f"of their cycles ({counters.get('counters_from', 'profiles/').strip()})")
+    return "; ".join(parts)
 
 
 def cpu_baseline(A, rf, target_madds):

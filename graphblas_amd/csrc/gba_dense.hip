@@ -380,7 +380,7 @@ static gba_info dot_sparse_dense(gba_matrix *C, const gba_matrix *M, bool Mask_c
                             }
                         }
                         trow = aux->tile_row[0];
-                        if (!aux->i32 && A->vlen < (int64_t)0x7fffffff) {
+                        if (!aux->i32 && A->vlen < (int64_t)0x7fffffff && A->nvals <= PATTERN_I32_MAX_ENTRIES) {
                             aux->i32 = reinterpret_cast<int32_t *>(gba_malloc((size_t)A->nvals * 4));
                             if (aux->i32) {
                                 int64_t nb = ceil_div(A->nvals, 1024); if (nb > 16384) nb = 16384;
@@ -931,7 +931,7 @@ static gba_info saxpy4_binned(S sr, const gba_matrix *A, const DenseView &Bv, in
             }
         }
         table = aux->bin_table; tile_rows = aux->bin_tile_rows; chunk_base = aux->bin_chunks;
-        if (!aux->i32 && A->vlen < (int64_t)0x7fffffff) {
+        if (!aux->i32 && A->vlen < (int64_t)0x7fffffff && A->nvals <= PATTERN_I32_MAX_ENTRIES) {
             aux->i32 = reinterpret_cast<int32_t *>(gba_malloc((size_t)A->nvals * 4));
             if (aux->i32) {
                 int64_t nbk = ceil_div(A->nvals, 1024); if (nbk > 16384) nbk = 16384;

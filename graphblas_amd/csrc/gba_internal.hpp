@@ -220,6 +220,8 @@ gba_info sorted_copy(const gba_matrix *X, gba_matrix *out, std::vector<void *> &
 // caller's view, so they are kept beside it, keyed by the addresses of p and i, nvals, nvec and vlen.  Only the
 // pattern is remembered (values may change freely).  An entry is dropped when one of its arrays is given back with
 // gba_free, by gba_matrix_forget, or when it is the least recently used of PATTERN_AUX_SLOTS.
+// a remembered 32-bit index copy is kept only for patterns of at most this many entries (4 GiB of copy)
+static constexpr int64_t PATTERN_I32_MAX_ENTRIES = (int64_t)1 << 30;
 struct PatternAux {
     const void *p = nullptr, *i = nullptr;
     int64_t nvals = 0, nvec = 0, vlen = 0;

@@ -6,8 +6,8 @@
 For the named kernel of the bench run: HBM bytes per launch (FETCH_SIZE and WRITE_SIZE are KiB; on gfx950
 FETCH_SIZE tallies 128-byte read requests at 64 bytes, so the bytes fetched are 2 * 1024 * FETCH_SIZE), the share
 of LDS cycles lost to bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE) and the waves resident per busy
-CU (4 * SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES: SQ_WAVE_CYCLES counts in units of four cycles).  The same three figures
-for the SpMV kernels go under "<workload> spmv"."""
+CU (4 * SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES: SQ_WAVE_CYCLES counts in units of four cycles), and the instruction
+issue figures bench.py words its `limiter` from.  The same figures for the SpMV kernels go under "<workload> spmv"."""
 import csv
 import json
 import os
@@ -33,6 +33,16 @@ def figures(r):
         rec["lds_bank_conflict_frac"] = round(f("SQ_LDS_BANK_CONFLICT") / f("SQ_LDS_IDX_ACTIVE"), 4)
     if f("SQ_WAVE_CYCLES") and f("SQ_BUSY_CU_CYCLES"):
         rec["waves_per_busy_cu"] = round(4 * f("SQ_WAVE_CYCLES") / f("SQ_BUSY_CU_CYCLES"), 2)
+    # instruction issue: wave-level instructions per launch, and the share of their resident cycles in which the waves
+    # issue (SQ_ACTIVE_INST_ANY) or wait on a counter (SQ_WAIT_ANY); both tally in the unit of SQ_WAVE_CYCLES
+    for key, name in (("SQ_INSTS_VALU", "insts_valu"), ("SQ_INSTS_SALU", "insts_salu"), ("SQ_INSTS_LDS", "insts_lds")):
+        if f(key):
+            rec[name] = int(f(key) / n)
+    if f("SQ_WAVE_CYCLES"):
+        if f("SQ_ACTIVE_INST_ANY"):
+            rec["wave_issue_frac"] = round(f("SQ_ACTIVE_INST_ANY") / f("SQ_WAVE_CYCLES"), 4)
+        if f("SQ_WAIT_ANY"):
+            rec["wave_wait_frac"] = round(f("SQ_WAIT_ANY") / f("SQ_WAVE_CYCLES"), 4)
     return rec
 
 
