@@ -121,6 +121,70 @@ def test_bfs_rmat22_levels_and_parents(gba):
     dA.free()
 
 
+def test_bfs_rmat24_validates_as_a_breadth_first_tree(gba):
+    """The same traversal at RMAT-24 (16.8M vertices, 2 x 2.6e8 directed edges after symmetrisation), checked the way
+    Graph500 validates a BFS without a second traversal: (1) the source is its own parent at level 0; (2) every
+    other reached vertex has a parent one level up with an edge to it; (3) the two ends of every edge are either
+    both reached with levels at most one apart, or both unreached.  By (2) the parents form a path of level(v)
+    edges from the source, so level(v) is at least the distance; by (3), walking a shortest path from the source,
+    the level grows by at most one per edge, so it is at most the distance: the levels are the distances."""
+    A = gen.rmat(24, 16, seed=42, type=Type.INT64, values="ones", symmetric=True, drop_diagonal=True)
+    n = A.nrows
+    deg = np.diff(A.p)
+    src = int(np.argmax(deg))
+    dA = A.to_device()
+    level_of = np.full(n, -1, np.int32); parent = np.full(n, -1, np.int64)
+    level_of[src] = 0; parent[src] = src
+    pi_b = np.zeros(n, np.int8); pi_x = np.zeros(n, np.int64)
+    pi_b[src] = 1; pi_x[src] = src
+    q = Matrix.sparse_vector(n, [src], np.array([src], np.int64))
+    for level in range(1, 64):
+        dq = q.to_device()
+        dpi = Matrix.bitmap_vector(pi_x, pi_b).to_device()
+        dw = Matrix.sparse_vector(n, [], np.zeros(0, np.int64)).to_device()
+        g.vxm(dw, dpi, None, "ANY_SECONDI_INT64", dq, dA, "RSC")
+        r, _, parents = dw.to_host().coo()
+        _free(dq, dpi, dw)
+        if len(r) == 0:
+            break
+        assert np.all(level_of[r] == -1), level                      # the mask kept visited vertices out
+        level_of[r] = level; parent[r] = parents
+        pi_b[r] = 1; pi_x[r] = parents
+        if len(r) > n // 8:
+            b = np.zeros(n, np.int8); x = np.zeros(n, np.int64); b[r] = 1; x[r] = parents
+            q = Matrix.bitmap_vector(x, b)
+        else:
+            q = Matrix.sparse_vector(n, r, parents)
+    dA.free()
+    reached = level_of >= 0
+    assert reached.sum() > n // 4 and level_of.max() >= 4
+    kids = np.flatnonzero(reached); kids = kids[kids != src]
+    assert np.all(level_of[parent[kids]] == level_of[kids] - 1)     # (2) one level up ...
+    # ... with an edge to the child: the child is in the parent's sorted row (every child, in slabs)
+    for lo in range(0, len(kids), 1 << 22):
+        c = kids[lo:lo + (1 << 22)]; pr = parent[c]
+        # position of c in row pr by a vectorised binary search over [A.p[pr], A.p[pr + 1])
+        a, b = A.p[pr].copy(), A.p[pr + 1].copy()
+        while True:
+            open_ = a < b
+            if not open_.any():
+                break
+            mid = (a + b) >> 1
+            less = np.zeros(len(c), bool)
+            less[open_] = A.i[mid[open_]] < c[open_]
+            a = np.where(open_ & less, mid + 1, a)
+            b = np.where(open_ & ~less, mid, b)
+        assert np.all(a < A.p[pr + 1]) and np.all(A.i[np.minimum(a, len(A.i) - 1)] == c)
+    # (3) over every edge, in slabs of rows
+    for lo in range(0, n, 1 << 21):
+        hi = min(lo + (1 << 21), n)
+        e0, e1 = int(A.p[lo]), int(A.p[hi])
+        lu = np.repeat(level_of[lo:hi], deg[lo:hi])
+        lv = level_of[A.i[e0:e1]]
+        assert np.all((lu >= 0) == (lv >= 0))
+        assert np.all(np.abs(lu - lv) <= 1)
+
+
 def test_sssp_rmat20_bellman_ford_bit_exact(gba):
     """d = min(d, d min.+ A) until it stops changing, MIN_PLUS_FP64 through gba_vxm with the MIN accumulator
     (saxpy4, in place).  Every candidate is one fp64 addition of the same two numbers on both sides and MIN is
