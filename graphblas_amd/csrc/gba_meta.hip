@@ -426,6 +426,39 @@ static gba_info make_wb_mask(const gba_matrix *M, bool comp, bool structural, Wb
     return GBA_SUCCESS;
 }
 
+// An iso-valued C (one stored value for all its entries, Source/GB_AxB_iso.c:79) that is about to be updated entry by
+// entry gets its values written out first: the reference does the same when the result cannot stay iso
+// (GB_convert_any_to_non_iso).
+__global__ void __launch_bounds__(256)
+spread_value_kernel(unsigned char *__restrict__ dst, const unsigned char *__restrict__ one, int size, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        for (int b = 0; b < size; b++) dst[e * size + b] = one[b];
+}
+
+static gba_info spread_iso_values(gba_matrix *C) {
+    if (!C->iso) return GBA_SUCCESS;
+    if (C->mem != GBA_MEM_DEVICE || !C->x) GBA_FAIL(GBA_INVALID_OBJECT, "iso-valued C without its value on the device");
+    const size_t zs = type_size(C->type);
+    int64_t n = (is_sparse(C) || is_hyper(C)) ? C->nvals : C->vlen * C->vdim;
+    if ((is_sparse(C) || is_hyper(C)) && C->p) {                // room for every position, zombies included
+        int64_t last = 0;
+        GBA_OK(dev_read_i64(C->p + C->nvec, &last));
+        if (last > n) n = last;
+    }
+    void *x = gba_malloc((size_t)(n > 0 ? n : 1) * zs);
+    if (!x) GBA_FAIL(GBA_OUT_OF_MEMORY, "values of an iso-valued C (%ld entries)", (long)n);
+    if (n > 0) {
+        int64_t blocks = ceil_div(n, (int64_t)256); if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(spread_value_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx().stream,
+                           reinterpret_cast<unsigned char *>(x), reinterpret_cast<const unsigned char *>(C->x), (int)zs, n);
+        GBA_HIP(hipGetLastError());
+        GBA_HIP(hipStreamSynchronize(ctx().stream));
+    }
+    gba_free(C->x);
+    C->x = x; C->iso = false;
+    return GBA_SUCCESS;
+}
+
 // C (bitmap or full, updated in place or converted to bitmap) <M> = accum (C, T)
 static gba_info writeback_dense(const Call &k, const gba_matrix *M, gba_matrix *T) {
     gba_matrix *C = k.C;
@@ -445,11 +478,9 @@ static gba_info writeback_dense(const Call &k, const gba_matrix *M, gba_matrix *
         GBA_HIP(hipMemsetAsync(newb.p, 1, (size_t)(n > 0 ? n : 1), st));
         Cb = newb.as<int8_t>();
     }
+    GBA_OK(spread_iso_values(C));
     void *Cx = C->x;
     DevBuf newx;
-    if (C->iso) {
-        GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back into an iso-valued C");
-    }
     // dense image of T
     DevBuf Db, Dx;
     const int8_t *Tb = nullptr; const void *Tx = T->x; bool T_iso = T->iso;
@@ -579,7 +610,7 @@ static gba_info writeback_sparse(const Call &k, const gba_matrix *M, gba_matrix 
     if (T->type != C->type) GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back with typecast (%d -> %d)", T->type, C->type);
     if (k.has_accum && (k.accum.type != C->type || !accum_op_ok(k.accum.op)))
         GBA_FAIL(GBA_NOT_IMPLEMENTED, "accum operator %d on type %d", k.accum.op, k.accum.type);
-    if (C->iso) GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back into an iso-valued C");
+    GBA_OK(spread_iso_values(C));
     if (C->jumbled || C->nzombies) GBA_OK(matrix_wait(C));
     if (T->jumbled || T->nzombies) GBA_OK(matrix_wait(T));
     const int64_t nvec = C->vdim;
@@ -624,7 +655,7 @@ static gba_info sparse_C_to_bitmap(gba_matrix *C, const Call &k) {
     hipStream_t st = ctx().stream;
     const int64_t n = C->vlen * C->vdim;
     if (C->vlen > 0 && n / C->vlen != C->vdim) GBA_FAIL(GBA_NOT_IMPLEMENTED, "bitmap form of C overflows");
-    if (C->iso) GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back into an iso-valued C");
+    GBA_OK(spread_iso_values(C));
     if (C->nzombies) GBA_OK(matrix_wait(C));
     const size_t zs = type_size(C->type);
     DevBuf Db, Dx;
@@ -1157,18 +1188,25 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only);
 // the front end itself as C<M> = accum (C, T*I) with the identity pattern I and ANY_FIRST, whose product is T
 // entry for entry.  Serves the products that had to be computed in one type family and cast to the other
 // (a complex product into a real C, a real product into a complex C).
+__global__ void __launch_bounds__(256) iota_kernel(int64_t *x, int64_t n) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) x[q] = q;
+}
+
 gba_info mxm_assign_cast(gba_matrix *C, const gba_matrix *M, const gba_binop *accum, bool C_replace, bool Mask_comp,
                          bool Mask_struct, const gba_matrix *T, gba_report *report) {
     hipStream_t st = ctx().stream;
     const int64_t n = T->is_csc ? T->vdim : T->vlen;          // columns of T
+    // the identity costs 16 bytes per column: declined where that alone would be tens of gigabytes
+    if (n > ((int64_t)1 << 31)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "typecast of a product with %ld vectors", (long)n);
     DevBuf Ip, Ii, Ix;
     GBA_OK(Ip.alloc((size_t)(n + 1) * 8)); GBA_OK(Ii.alloc((size_t)(n > 0 ? n : 1) * 8)); GBA_OK(Ix.alloc(16));
-    std::vector<int64_t> iota((size_t)n + 1);
-    for (int64_t q = 0; q <= n; q++) iota[(size_t)q] = q;
-    GBA_HIP(hipMemcpyAsync(Ip.p, iota.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
-    GBA_HIP(hipMemcpyAsync(Ii.p, iota.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    {
+        int64_t blocks = ceil_div(n + 1, (int64_t)256); if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Ip.as<int64_t>(), n + 1);
+        if (n > 0) hipLaunchKernelGGL(iota_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Ii.as<int64_t>(), n);
+    }
     GBA_HIP(hipMemsetAsync(Ix.p, 0, 16, st));
-    GBA_HIP(hipStreamSynchronize(st));
+    GBA_HIP(hipGetLastError());
     gba_matrix I{};
     I.vlen = I.vdim = I.nvec = I.nvals = n;
     I.p = Ip.as<int64_t>(); I.i = Ii.as<int64_t>(); I.x = Ix.p;

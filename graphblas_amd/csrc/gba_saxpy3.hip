@@ -2346,7 +2346,10 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     // the caller then multiplies without it and applies it in the write-back.  The reference's rule
     // (Source/GB_AxB_saxpy3_slice_balanced.c:22, 309-403): discard when flops < 0.01 * (entries of M in the vectors
     // that B fills).
-    if (may_discard_mask && M && is_sparse(M) && nvec > 0) {
+    // A mask that is bitmap, full, or sparse with every entry present is always applied (slice_balanced.c:319), and so
+    // is one too small for the rule to ever fire; neither costs the count below and its trip to the host.
+    const bool m_as_if_full = M && M->nvals == M->vlen * M->vdim;
+    if (may_discard_mask && M && is_sparse(M) && !m_as_if_full && M->nvals >= 100 && nvec > 0) {
         DevBuf w; GBA_OK(w.alloc(16));
         GBA_HIP(hipMemsetAsync(w.p, 0, 16, st));
         int64_t blocks = ceil_div(nvec, 256); if (blocks > 512) blocks = 512;

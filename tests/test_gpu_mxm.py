@@ -443,3 +443,33 @@ def test_a_hypersparse_C_is_untouched_by_a_call_that_fails(gba, failure):
     assert np.array_equal(back.i, C0.i) and np.array_equal(back.x, C0.x)
     for d in (dC, dA, dB):
         d.free()
+
+
+@pytest.mark.parametrize("ckind", ["sparse", "full", "bitmap"])
+@pytest.mark.parametrize("accum,masked", [("PLUS_FP64", False), ("MIN_FP64", True), (None, True)])
+def test_an_iso_valued_C_comes_in(gba, ckind, accum, masked):
+    """C<M> = accum (C, A*B) where C arrives iso-valued (one stored value for all its entries, as an earlier iso
+    product or GrB_assign of a scalar leaves it; Source/GB_AxB_iso.c:79, Source/GB_accum_mask.c): the result is that
+    of the same C with its values written out."""
+    n = 60
+    A, B = _rand(n, n, 0.1, 41), _rand(n, n, 0.1, 42)
+    M = _rand(n, n, 0.3, 43) if masked else None
+    if ckind == "sparse":
+        P = _rand(n, n, 0.2, 44)
+        C_iso = Matrix(P.vlen, P.vdim, Type.FP64, Sparsity.SPARSE, P.is_csc, p=P.p, i=P.i, x=np.array([2.5]), iso=True, nvals=P.nvals)
+        C_out = Matrix(P.vlen, P.vdim, Type.FP64, Sparsity.SPARSE, P.is_csc, p=P.p, i=P.i, x=np.full(P.nvals, 2.5))
+    elif ckind == "full":
+        C_iso = Matrix(n, n, Type.FP64, Sparsity.FULL, True, x=np.array([2.5]), iso=True)
+        C_out = Matrix(n, n, Type.FP64, Sparsity.FULL, True, x=np.full(n * n, 2.5))
+    else:
+        b = (np.random.default_rng(45).random(n * n) < 0.4).astype(np.int8)
+        C_iso = Matrix(n, n, Type.FP64, Sparsity.BITMAP, True, x=np.array([2.5]), b=b, iso=True)
+        C_out = Matrix(n, n, Type.FP64, Sparsity.BITMAP, True, x=np.full(n * n, 2.5), b=b)
+    dA, dB, dC = A.to_device(), B.to_device(), C_iso.to_device()
+    dM = M.to_device() if masked else None
+    gba.mxm(dC, dM, accum, "PLUS_TIMES_FP64", dA, dB, "")
+    p, v = oracle.mxm_spec(C_out, M, accum, "PLUS_TIMES_FP64", A, B, "")
+    assert_dense_same(dC.to_host(), p, v, exact=True, what=f"iso C {ckind}/{accum}/{masked}")
+    for d in (dA, dB, dC, dM):
+        if d is not None:
+            d.free()
