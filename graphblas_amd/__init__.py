@@ -13,7 +13,7 @@ from .binding import (  # noqa: F401
     semiring, binop, descriptor, init, finalize, NP_TYPES, TYPE_OF_NP,
 )
 from .host import (  # noqa: F401
-    Matrix, DeviceMatrix, mxm, mxv, vxm, mxm_select, mxm_udt, register_udt, user_semiring,
+    Matrix, DeviceMatrix, mxm, mxv, vxm, mxm_select, mxm_udt, vxm_udt, register_udt, user_semiring,
     AxB_saxpy3, AxB_saxpy3_flopcount, AxB_dot3, AxB_dot2, AxB_dot4, AxB_saxpy4, AxB_saxpy5, AxB_saxbit,
     cumsum, matrix_wait, matrix_forget, transpose, partition_by_flops, sync, timer_start, timer_stop,
 )

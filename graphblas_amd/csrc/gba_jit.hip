@@ -37,7 +37,7 @@ static std::string device_function(const char *defn) {
     return std::string("__device__ inline ") + defn + "\n";
 }
 
-static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, const char *accum_defn, JitKernels *out) {
+static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, const char *accum_defn, bool flip_mult, JitKernels *out) {
     std::string src;
     src += "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
            "typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;\n";
@@ -46,7 +46,14 @@ static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, co
     if (std::string(s->mult_defn) != s->add_defn) src += device_function(s->mult_defn);
     const bool own_accum = accum_defn && std::string(accum_defn) != s->add_defn && std::string(accum_defn) != s->mult_defn;
     if (own_accum) src += device_function(accum_defn);
-    const std::string T = s->type_name, ADD = s->add_name, MULT = s->mult_name, ACC = accum_name ? accum_name : s->add_name;
+    const std::string T = s->type_name, ADD = s->add_name, ACC = accum_name ? accum_name : s->add_name;
+    std::string MULT = s->mult_name;
+    if (flip_mult) {
+        // z = f (y, x): a user-defined multiplier cannot be rewritten, so its operands are handed over in the other
+        // order (Source/GB_flip_binop.c:355-375 leaves flipxy set for such an operator)
+        MULT = std::string("gba_flipped_") + s->mult_name;
+        src += "__device__ inline void " + MULT + " (" + T + " *z, const " + T + " *x, const " + T + " *y) { " + s->mult_name + " (z, y, x) ; }\n";
+    }
     src +=
         "extern \"C\" __global__ void gba_udt_dot (int64_t nvec, int64_t tnz, const int64_t *Tp, const int64_t *Ti, " + T + " *Tx,\n"
         "    const int64_t *Ap, const int64_t *Ai, const " + T + " *Ax, int A_iso,\n"
@@ -261,7 +268,7 @@ static gba_matrix pattern_view(const gba_matrix &S) {
 
 static gba_info mxm_udt_body(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
                  const gba_user_semiring *s, const gba_matrix *A, const gba_matrix *B, const gba_descriptor *desc,
-                 gba_report *report) {
+                 gba_report *report, bool flip_mult) {
     GBA_OK(require_init());
     if (!C || !s || !A || !B) GBA_FAIL(GBA_NULL_POINTER, "gba_mxm_udt: null argument");
     if (!s->type_name || !s->type_defn || !s->add_name || !s->add_defn || !s->mult_name || !s->mult_defn || s->type_size == 0)
@@ -289,7 +296,7 @@ static gba_info mxm_udt_body(gba_matrix *C, const gba_matrix *M, const char *acc
     KernelTimer timer(report != nullptr);
 
     JitKernels jit;
-    GBA_OK(jit_build(s, accum_name, accum_defn, &jit));
+    GBA_OK(jit_build(s, accum_name, accum_defn, flip_mult, &jit));
 
     struct Owned { std::vector<void *> v; ~Owned() { for (void *p : v) gba_free(p); } } own;
     // hypersparse mask and C: the sparse form of the same matrix (a pointer per vector); a C that came in
@@ -394,10 +401,10 @@ static gba_info mxm_udt_body(gba_matrix *C, const gba_matrix *M, const char *acc
 
 gba_info mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
                  const gba_user_semiring *s, const gba_matrix *A, const gba_matrix *B, const gba_descriptor *desc,
-                 gba_report *report) {
+                 gba_report *report, bool flip_mult) {
     // a call that fails or is declined after a hypersparse C was expanded hands C back hypersparse, as it came
     const bool C_was_hyper = C && is_hyper(C);
-    const gba_info info = mxm_udt_body(C, M, accum_name, accum_defn, s, A, B, desc, report);
+    const gba_info info = mxm_udt_body(C, M, accum_name, accum_defn, s, A, B, desc, report, flip_mult);
     if (info != GBA_SUCCESS && C_was_hyper && is_sparse(C) && C->mem == GBA_MEM_DEVICE) {
         const std::string keep = last_error();
         if (sparse_to_hyper(C) == GBA_SUCCESS) set_error("%s", keep.c_str());
@@ -575,7 +582,7 @@ gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
     d.mask = Mask_comp ? (Mask_struct ? GBA_COMP_STRUCTURE : GBA_COMP) : (Mask_struct ? GBA_STRUCTURE : GBA_DEFAULT);
     d.in0 = A_tran ? GBA_TRAN : GBA_DEFAULT; d.in1 = B_tran ? GBA_TRAN : GBA_DEFAULT;
     const gba_info info = mxm_udt(&Cv, M ? &Mv : nullptr, has_accum ? acc_name.c_str() : nullptr, has_accum ? acc_defn.c_str() : nullptr,
-                                  &us, &Av, &Bv, &d, report);
+                                  &us, &Av, &Bv, &d, report, false);
     Cv.type = zt;
     *C = Cv;                    // on failure mxm_udt leaves the view as it was
     if (report && info == GBA_SUCCESS) report->typecast = typecast;
@@ -587,5 +594,17 @@ gba_info mxm_complex(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,
 extern "C" gba_info gba_mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name, const char *accum_defn,
                                 const gba_user_semiring *semiring, const gba_matrix *A, const gba_matrix *B,
                                 const gba_descriptor *desc, gba_report *report) {
-    return gba::mxm_udt(C, M, accum_name, accum_defn, semiring, A, B, desc, report);
+    return gba::mxm_udt(C, M, accum_name, accum_defn, semiring, A, B, desc, report, false);
+}
+
+extern "C" gba_info gba_vxm_udt(gba_matrix *w, const gba_matrix *mask, const char *accum_name, const char *accum_defn,
+                                const gba_user_semiring *semiring, const gba_matrix *u, const gba_matrix *A,
+                                const gba_descriptor *desc, gba_report *report) {
+    // w' = u'*A is w = A'*u with the multiplier's operands exchanged (Source/GrB_vxm.c:63-72); GrB_vxm reads the
+    // transpose setting of A from INP1 and ignores INP0
+    gba_descriptor d{};
+    if (desc) d = *desc;
+    d.in0 = (d.in1 == GBA_TRAN) ? GBA_DEFAULT : GBA_TRAN;
+    d.in1 = GBA_DEFAULT;
+    return gba::mxm_udt(w, mask, accum_name, accum_defn, semiring, A, u, &d, report, true);
 }

@@ -306,6 +306,16 @@ def mxm_udt(C_, Mask, accum, semiring, A, B, desc=None):
     return rep
 
 
+def vxm_udt(w, mask, accum, semiring, u, A, desc=None):
+    """w'<mask'> = accum (w', u'*A) over a user-defined semiring (the multiplier sees its operands as z = f (u(k), A(k,j)))."""
+    rep = gba_report()
+    d = _desc(desc)
+    an, ad = (accum[0].encode(), accum[1].encode()) if accum else (None, None)
+    lib.check(lib.gba_vxm_udt(w.ref(), _ref(mask), an, ad, C.byref(semiring), u.ref(), A.ref(),
+                              C.byref(d) if d is not None else None, C.byref(rep)))
+    return rep
+
+
 def mxm_select(C_, Mask, accum, semiring, A, B, desc=None):
     """Method the dispatcher would take for this GrB_mxm call (no compute)."""
     return _call3(lib.gba_mxm_select, C_, Mask, accum, semiring, A, B, desc)

@@ -295,6 +295,15 @@ gba_info gba_mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name,
                      const gba_user_semiring *semiring, const gba_matrix *A, const gba_matrix *B,
                      const gba_descriptor *desc, gba_report *report);
 
+/* w'<mask'> = accum (w', u'*A) over a user-defined semiring: GrB_vxm for the type GBA_UDT (Source/GrB_vxm.c:63-72).
+ * Computed as w = A'*u with the operands of the multiplier exchanged, z = mult (y, x): a user-defined multiplier
+ * is not rewritten, the reference passes its operands in the other order as well
+ * (Source/GB_flip_binop.c:355-375).  desc->in1 is the transpose setting of A, desc->in0 is ignored, as in GrB_vxm.
+ * Otherwise as gba_mxm_udt. */
+gba_info gba_vxm_udt(gba_matrix *w, const gba_matrix *mask, const char *accum_name, const char *accum_defn,
+                     const gba_user_semiring *semiring, const gba_matrix *u, const gba_matrix *A,
+                     const gba_descriptor *desc, gba_report *report);
+
 /* w<mask> = accum (w, A*u)   -- GrB_mxv (Include/GraphBLAS.h:4662-4671, Source/GrB_mxv.c:18) */
 gba_info gba_mxv(gba_matrix *w, const gba_matrix *mask, const gba_binop *accum,
                  const gba_semiring *semiring, const gba_matrix *A, const gba_matrix *u,

@@ -520,12 +520,13 @@ static bool shim_binop_is_over (GrB_BinaryOp op, int32_t code)
         && GrB_BinaryOp_get_INT32 (op, &yc, GrB_INP1_TYPE_CODE) == GrB_SUCCESS && yc == code) ;
 }
 
-/* C<M> = accum (C, A*B) (which == 0) or w<m> = accum (w, A*u) (which == 2) over a semiring of one user-defined
- * type.  Same contract as shim_run. */
+/* C<M> = accum (C, A*B) (which == 0), w'<m'> = accum (w', u'*A) (which == 1: gba_vxm_udt exchanges the operands of
+ * the multiplier) or w<m> = accum (w, A*u) (which == 2) over a semiring of one user-defined type.  Same contract as
+ * shim_run. */
 static bool shim_run_udt (int which, shim_call *k, const GrB_BinaryOp accum,
     const GrB_Semiring semiring, const GrB_Descriptor desc)
 {
-    if (which == 1 || semiring == NULL) return (false) ;           /* vxm flips the multiplier: left to the CPU */
+    if (semiring == NULL) return (false) ;
     if (k->c->v.type != GBA_UDT || k->a->v.type != GBA_UDT || k->b->v.type != GBA_UDT || k->c->v.iso) return (false) ;
     GrB_Type tc, ta, tb ;
     if (!shim_operand_type (&tc, k->c) || !shim_operand_type (&ta, k->a) || !shim_operand_type (&tb, k->b)
@@ -570,8 +571,10 @@ static bool shim_run_udt (int which, shim_call *k, const GrB_BinaryOp accum,
         gba_user_semiring us ;
         us.type_name = str [0] ; us.type_defn = str [1] ; us.type_size = tsize ;
         us.add_name = str [2] ; us.add_defn = str [3] ; us.mult_name = str [4] ; us.mult_defn = str [5] ;
-        const gba_info info = gba_mxm_udt (&cdev, k->has_mask ? &(dev [k->m - k->ops]) : NULL, str [6], str [7], &us,
-            &(dev [k->a - k->ops]), &(dev [k->b - k->ops]), &d, NULL) ;
+        const gba_matrix *dm = k->has_mask ? &(dev [k->m - k->ops]) : NULL ;
+        const gba_info info = (which == 1)
+            ? gba_vxm_udt (&cdev, dm, str [6], str [7], &us, &(dev [k->a - k->ops]), &(dev [k->b - k->ops]), &d, NULL)
+            : gba_mxm_udt (&cdev, dm, str [6], str [7], &us, &(dev [k->a - k->ops]), &(dev [k->b - k->ops]), &d, NULL) ;
         taken = (info == GBA_SUCCESS) && shim_download (k->c, &cdev) ;
     }
     gba_matrix_free_content (&cdev) ;

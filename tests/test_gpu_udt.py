@@ -240,3 +240,55 @@ def test_gauss_into_a_sparse_C_that_holds_entries(gba, desc, with_accum):
     w = np.where(mp, z, cc)
     assert np.array_equal(gp, wp), desc
     assert np.array_equal(got[wp], w[wp]), desc
+
+
+AFFINE_DEFN = "typedef struct { int32_t a ; int32_t b ; } affine ;"
+AFFINE_ADD = """void addaffine (affine *z, const affine *x, const affine *y)
+{
+    z->a = x->a + y->a ;
+    z->b = x->b + y->b ;
+}"""
+# composition of x -> a x + b maps: not commutative, so the order of the operands shows
+AFFINE_MULT = """void compose (affine *z, const affine *x, const affine *y)
+{
+    int32_t a = x->a * y->a ;
+    int32_t b = x->a * y->b + x->b ;
+    z->a = a ;
+    z->b = b ;
+}"""
+
+
+@pytest.mark.parametrize("tran", [False, True])
+def test_vxm_over_a_user_type_hands_the_multiplier_its_operands_in_vxm_order(gba, tran):
+    """w' = u'*A with a multiplier that does not commute: every term is compose (u(k), A(k,j)), the vector's entry
+    first (Source/GrB_vxm.c:63-72 computes A'*u with the operands exchanged, Source/GB_flip_binop.c:355-375)."""
+    dt = g.register_udt(np.dtype([("a", "<i4"), ("b", "<i4")]))
+    sr = g.user_semiring("affine", AFFINE_DEFN, dt.itemsize, "addaffine", AFFINE_ADD, "compose", AFFINE_MULT)
+    n = 40
+    rng = np.random.default_rng(11)
+    dense = rng.random((n, n)) < 0.2
+    rows, cols = np.nonzero(dense)
+    ax = np.zeros(len(rows), dtype=dt); ax["a"] = rng.integers(-3, 4, len(rows)); ax["b"] = rng.integers(-3, 4, len(rows))
+    p = np.zeros(n + 1, np.int64); np.add.at(p, rows + 1, 1)
+    A = Matrix(n, n, Type.UDT, Sparsity.SPARSE, False, p=np.cumsum(p), i=cols, x=ax)          # by row
+    uk = np.flatnonzero(rng.random(n) < 0.5)
+    ux = np.zeros(len(uk), dtype=dt); ux["a"] = rng.integers(-3, 4, len(uk)); ux["b"] = rng.integers(-3, 4, len(uk))
+    u = Matrix(n, 1, Type.UDT, Sparsity.SPARSE, True, p=np.array([0, len(uk)], np.int64), i=uk, x=ux)
+    w = Matrix(n, 1, Type.UDT, Sparsity.SPARSE, True, p=np.zeros(2, np.int64), i=np.zeros(0, np.int64), x=np.zeros(0, dt))
+    dA, du, dw = A.to_device(), u.to_device(), w.to_device()
+    g.vxm_udt(dw, None, None, sr, du, dA, "T1" if tran else None)
+    r, _, v = dw.to_host().coo()
+    want = {}
+    uval = {int(k): (int(x["a"]), int(x["b"])) for k, x in zip(uk, ux)}
+    for i, j, x in zip(rows, cols, ax):
+        k, out = (int(j), int(i)) if tran else (int(i), int(j))         # A'(k,out) = A(out,k)
+        if k in uval:
+            xa, xb = uval[k]
+            ta, tb = xa * int(x["a"]), xa * int(x["b"]) + xb
+            sa, sb = want.get(out, (0, 0))
+            want[out] = (sa + ta, sb + tb)
+    assert sorted(want) == [int(q) for q in r]
+    for q, e in zip(r, v):
+        assert (int(e["a"]), int(e["b"])) == want[int(q)], int(q)
+    for d in (dA, du, dw):
+        d.free()
