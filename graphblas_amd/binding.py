@@ -205,6 +205,7 @@ class _Lib:
             "gba_vxm": (i32, [M, M, B, S, M, M, D, R]),
             "gba_mxm_select": (i32, [M, M, B, S, M, M, D, R]),
             "gba_mxm_udt": (i32, [M, M, C.c_char_p, C.c_char_p, P(gba_user_semiring), M, M, D, R]),
+            "gba_jit_stats": (i32, [P(C.c_uint64), P(C.c_uint64)]),
             "gba_vxm_udt": (i32, [M, M, C.c_char_p, C.c_char_p, P(gba_user_semiring), M, M, D, R]),
             "gba_AxB_saxpy3": (i32, [M, M, b, b, M, M, S, i32, i32, P(b), R]),
             "gba_AxB_saxpy3_flopcount": (i32, [P(i64), vp, M, b, M, M]),

@@ -10,6 +10,10 @@
 // and add called in the order the CPU's dot kernels use (Source/Template/GB_AxB_dot_cij.c).  No atomics
 // are needed, so any type size works.
 #include "gba_internal.hpp"
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cstdio>
+#include <cstring>
 #include <hip/hiprtc.h>
 #include <map>
 #include <mutex>
@@ -30,6 +34,67 @@ void jit_unload_all() {
     std::lock_guard<std::mutex> lock(g_jit_mu);
     for (auto &e : g_jit_cache) hipModuleUnload(e.second.module);
     g_jit_cache.clear();
+}
+
+// ---- code objects kept on disk ----------------------------------------------------------------------------------
+// Folder: $GBA_JIT_CACHE, else $HOME/.cache/graphblas_amd; GBA_JIT_CACHE set to an empty string or to 0 turns the disk
+// cache off.  File: <128-bit FNV-1a of the identity>.co = magic, length and text of the identity, length and bytes of
+// the code object.  A file whose identity text differs (a hash collision, another version's layout) is not used.  Any
+// failure to read or write only means that the kernel is compiled.
+static unsigned long long g_jit_compiles = 0, g_jit_disk_hits = 0;
+static const char JIT_FILE_MAGIC[8] = {'g', 'b', 'a', 'j', 'i', 't', '0', '1'};
+
+static std::string jit_disk_folder() {
+    const char *e = getenv("GBA_JIT_CACHE");
+    if (e) return (e[0] == '\0' || std::string(e) == "0") ? std::string() : std::string(e);
+    const char *home = getenv("HOME");
+    return (home && home[0]) ? std::string(home) + "/.cache/graphblas_amd" : std::string();
+}
+
+static std::string jit_disk_path(const std::string &identity) {
+    const std::string folder = jit_disk_folder();
+    if (folder.empty()) return std::string();
+    unsigned long long h[2] = {0xcbf29ce484222325ull, 0x84222325cbf29ce4ull};
+    for (unsigned char ch : identity) {
+        h[0] = (h[0] ^ ch) * 0x100000001b3ull;
+        h[1] = (h[1] ^ (unsigned char)(ch + 0x5b)) * 0x100000001b3ull;
+    }
+    char name[40];
+    snprintf(name, sizeof(name), "%016llx%016llx.co", h[0], h[1]);
+    return folder + "/" + name;
+}
+
+static bool jit_disk_load(const std::string &identity, std::string *code) {
+    const std::string path = jit_disk_path(identity);
+    if (path.empty()) return false;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    char magic[8]; unsigned long long n = 0;
+    if (fread(magic, 1, 8, f) == 8 && memcmp(magic, JIT_FILE_MAGIC, 8) == 0 && fread(&n, 8, 1, f) == 1 && n == identity.size()) {
+        std::string text(n, '\0');
+        if (fread(&text[0], 1, n, f) == n && text == identity && fread(&n, 8, 1, f) == 1 && n > 0 && n < (1ull << 30)) {
+            code->assign(n, '\0');
+            ok = fread(&(*code)[0], 1, n, f) == n;
+        }
+    }
+    fclose(f);
+    return ok;
+}
+
+static void jit_disk_store(const std::string &identity, const std::string &code) {
+    const std::string path = jit_disk_path(identity);
+    if (path.empty()) return;
+    const std::string folder = jit_disk_folder();
+    for (size_t at = 1; at <= folder.size(); at++)                       // mkdir -p
+        if (at == folder.size() || folder[at] == '/') (void)mkdir(folder.substr(0, at).c_str(), 0755);
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    unsigned long long n1 = identity.size(), n2 = code.size();
+    const bool ok = fwrite(JIT_FILE_MAGIC, 1, 8, f) == 8 && fwrite(&n1, 8, 1, f) == 1 && fwrite(identity.data(), 1, n1, f) == n1
+                 && fwrite(&n2, 8, 1, f) == 1 && fwrite(code.data(), 1, n2, f) == n2;
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());   // whole file or none
 }
 
 static std::string device_function(const char *defn) {
@@ -143,24 +208,35 @@ static gba_info jit_build(const gba_user_semiring *s, const char *accum_name, co
     auto it = g_jit_cache.find(key);
     if (it != g_jit_cache.end()) { *out = it->second; return GBA_SUCCESS; }
 
-    hiprtcProgram prog;
-    GBA_RTC(hiprtcCreateProgram(&prog, src.c_str(), "gba_udt.hip", 0, nullptr, nullptr));
     hipDeviceProp_t prop;
     GBA_HIP(hipGetDeviceProperties(&prop, ctx().device));
     const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
-    const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off"};
-    const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
-    if (cr != HIPRTC_SUCCESS) {
-        size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
-        std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
+    // what the code object depends on: the target, the options and the source.  Kept on disk under that identity, so a
+    // later process loads the code object instead of compiling (the reference keeps its compiled kernels the same
+    // way, Source/GB_jitifyer.c: a cache folder, one file per kernel, checked against its source when loaded).
+    const std::string identity = arch + " -O3 -ffp-contract=off\n" + src;
+    std::string code;
+    const bool from_disk = jit_disk_load(identity, &code);
+    if (!from_disk) {
+        hiprtcProgram prog;
+        GBA_RTC(hiprtcCreateProgram(&prog, src.c_str(), "gba_udt.hip", 0, nullptr, nullptr));
+        const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off"};
+        const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
+        if (cr != HIPRTC_SUCCESS) {
+            size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
+            std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
+            hiprtcDestroyProgram(&prog);
+            GBA_FAIL(GBA_INVALID_VALUE, "the user-defined semiring does not compile: %.600s", log.c_str());
+        }
+        size_t csize = 0;
+        GBA_RTC(hiprtcGetCodeSize(prog, &csize));
+        code.assign(csize, '\0');
+        GBA_RTC(hiprtcGetCode(prog, &code[0]));
         hiprtcDestroyProgram(&prog);
-        GBA_FAIL(GBA_INVALID_VALUE, "the user-defined semiring does not compile: %.600s", log.c_str());
+        jit_disk_store(identity, code);
     }
-    size_t csize = 0;
-    GBA_RTC(hiprtcGetCodeSize(prog, &csize));
-    std::string code(csize, '\0');
-    GBA_RTC(hiprtcGetCode(prog, &code[0]));
-    hiprtcDestroyProgram(&prog);
+    g_jit_compiles += from_disk ? 0 : 1;
+    g_jit_disk_hits += from_disk ? 1 : 0;
     JitKernels k;
     GBA_HIP(hipModuleLoadData(&k.module, code.data()));
     GBA_HIP(hipModuleGetFunction(&k.dot, k.module, "gba_udt_dot"));
@@ -595,6 +671,13 @@ extern "C" gba_info gba_mxm_udt(gba_matrix *C, const gba_matrix *M, const char *
                                 const gba_user_semiring *semiring, const gba_matrix *A, const gba_matrix *B,
                                 const gba_descriptor *desc, gba_report *report) {
     return gba::mxm_udt(C, M, accum_name, accum_defn, semiring, A, B, desc, report, false);
+}
+
+extern "C" gba_info gba_jit_stats(uint64_t *compiled, uint64_t *loaded_from_disk) {
+    std::lock_guard<std::mutex> lock(gba::g_jit_mu);
+    if (compiled) *compiled = gba::g_jit_compiles;
+    if (loaded_from_disk) *loaded_from_disk = gba::g_jit_disk_hits;
+    return GBA_SUCCESS;
 }
 
 extern "C" gba_info gba_vxm_udt(gba_matrix *w, const gba_matrix *mask, const char *accum_name, const char *accum_defn,

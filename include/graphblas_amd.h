@@ -295,6 +295,11 @@ gba_info gba_mxm_udt(gba_matrix *C, const gba_matrix *M, const char *accum_name,
                      const gba_user_semiring *semiring, const gba_matrix *A, const gba_matrix *B,
                      const gba_descriptor *desc, gba_report *report);
 
+/* How many user-defined or complex semirings this process compiled with hipRTC, and how many it loaded as code
+ * objects from the on-disk cache instead ($GBA_JIT_CACHE, else $HOME/.cache/graphblas_amd; GBA_JIT_CACHE empty or 0
+ * turns the disk cache off).  The reference keeps its JIT kernels on disk the same way (Source/GB_jitifyer.c). */
+gba_info gba_jit_stats(uint64_t *compiled, uint64_t *loaded_from_disk);
+
 /* w'<mask'> = accum (w', u'*A) over a user-defined semiring: GrB_vxm for the type GBA_UDT (Source/GrB_vxm.c:63-72).
  * Computed as w = A'*u with the operands of the multiplier exchanged, z = mult (y, x): a user-defined multiplier
  * is not rewritten, the reference passes its operands in the other order as well

@@ -292,3 +292,46 @@ def test_vxm_over_a_user_type_hands_the_multiplier_its_operands_in_vxm_order(gba
         assert (int(e["a"]), int(e["b"])) == want[int(q)], int(q)
     for d in (dA, du, dw):
         d.free()
+
+
+_DISK_WORKER = r"""
+import ctypes, json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import graphblas_amd as g
+from graphblas_amd import Matrix, Type, Sparsity
+from graphblas_amd.binding import lib
+sys.path.insert(0, sys.argv[1] + "/tests")
+import test_gpu_udt as t
+g.init(0)
+dt = g.register_udt(np.dtype([("real", "<i4"), ("imag", "<i4")]))
+sr = g.user_semiring("gauss", t.GAUSS_DEFN, dt.itemsize, "addgauss", t.ADD_DEFN, "multgauss", t.MULT_DEFN)
+A = t._gauss_matrix(dt, {(i, j): (i + 1, 2 - j) for i in range(4) for j in range(4) if (i, j) != (0, 0)})
+dA = A.to_device()
+dC = Matrix(4, 4, Type.UDT, Sparsity.SPARSE, False, p=np.zeros(5, np.int64), i=np.zeros(0, np.int64), x=np.zeros(0, dt)).to_device()
+g.mxm_udt(dC, None, None, sr, dA, dA)
+a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+lib.gba_jit_stats(ctypes.byref(a), ctypes.byref(b))
+print(json.dumps({"compiled": a.value, "from_disk": b.value, "C": t._as_table(dC.to_host())}))
+"""
+
+
+def test_compiled_semirings_are_kept_on_disk(gba, tmp_path):
+    """The first process compiles the semiring and leaves the code object in the cache folder; the second process
+    loads it from there without compiling and computes the same product."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GBA_JIT_CACHE=str(tmp_path / "jit"))
+    runs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", _DISK_WORKER, root], capture_output=True, text=True, timeout=240, env=env)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        runs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    assert runs[0]["compiled"] >= 1 and runs[0]["from_disk"] == 0
+    assert runs[1]["compiled"] == 0 and runs[1]["from_disk"] >= 1
+    assert runs[0]["C"] == runs[1]["C"]
+    assert any(f.suffix == ".co" for f in (tmp_path / "jit").iterdir())
+    off = subprocess.run([sys.executable, "-c", _DISK_WORKER, root], capture_output=True, text=True, timeout=240,
+                         env=dict(env, GBA_JIT_CACHE="0"))
+    assert off.returncode == 0 and json.loads(off.stdout.splitlines()[-1])["compiled"] >= 1
