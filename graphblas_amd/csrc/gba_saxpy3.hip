@@ -990,7 +990,13 @@ team_gather_kernel(int64_t nf, const uint64_t *__restrict__ Hf, const typename S
 // into A(:,k), the index stored at the cursor, and the end of A(:,k).  A
 // neighbour with nothing inside the panel is dismissed from those coalesced
 // arrays alone, without touching A.
+#ifdef GBA_PANEL_HALF
+static constexpr int PANEL_THREADS = 512;
+static constexpr int PANEL_WG_PER_CU = 2;
+#else
 static constexpr int PANEL_THREADS = 1024;
+static constexpr int PANEL_WG_PER_CU = 1;
+#endif
 static constexpr int PANEL_NPT = 1;                                   // neighbours searched per thread per step
 static constexpr int PANEL_STEP = PANEL_THREADS * PANEL_NPT;
 static constexpr int PANEL_SEGCAP = PANEL_THREADS;                    // runs queued in LDS before they are expanded: one search step's worth (LDS spent on
@@ -998,15 +1004,21 @@ static constexpr int PANEL_SEGCAP = PANEL_THREADS;                    // runs qu
 static constexpr int PANEL_UNROLL_MAX = 8;
 // two windows per wave in flight (the loads of one issued before the other is consumed)?
 static constexpr bool SYM_PANEL_PIPELINE = false, NUM_PANEL_PIPELINE = false;
-static constexpr int SYM_PANEL_UNROLL = 8, NUM_PANEL_UNROLL = 4;            // products in flight per thread
+#ifndef GBA_NUM_UNROLL
+#define GBA_NUM_UNROLL 4
+#endif
+#ifndef GBA_SYM_UNROLL
+#define GBA_SYM_UNROLL 8
+#endif
+static constexpr int SYM_PANEL_UNROLL = GBA_SYM_UNROLL, NUM_PANEL_UNROLL = GBA_NUM_UNROLL;            // products in flight per thread
 static constexpr int PANEL_T_BITS = 24;
 static constexpr int64_t PANEL_MAX_DEG = (int64_t)1 << PANEL_T_BITS;
 static constexpr int64_t PANEL_MAX_WIDTH = (int64_t)1 << 20;          // (SEGCAP-1) runs of this length stay below 2^32
-static constexpr int SYM_PANEL_WORDS = 32768;                         // 128 KiB of LDS
+static constexpr int SYM_PANEL_WORDS = 32 * PANEL_THREADS;             // 128 KiB of LDS
 static constexpr int64_t SYM_PANEL_WIDTH = (int64_t)SYM_PANEL_WORDS * 32;
-static constexpr int NUM_PANEL_SLOTS = 11264;                        // (any multiple of PANEL_THREADS: slots are picked by multiply-shift)
+static constexpr int NUM_PANEL_SLOTS = 11 * PANEL_THREADS;                        // (any multiple of PANEL_THREADS: slots are picked by multiply-shift)
 static constexpr int NUM_PANEL_TARGET = 3000;                         // distinct indices aimed at per panel (no boundaries known)
-static constexpr int NUM_PANEL_FIT = 8448;                            // entries between two recorded boundaries: three quarters of the slots
+static constexpr int NUM_PANEL_FIT = NUM_PANEL_SLOTS / 4 * 3;                            // entries between two recorded boundaries: three quarters of the slots
 static constexpr int SYM_WORDS_PER_THREAD = SYM_PANEL_WORDS / PANEL_THREADS;
 // The bitmap is stored with one word of padding after every thread's slice: slice t starts at word t * (SWPT + 1).
 // In the passes that count, list and clear the bitmap every thread walks its own slice; without the padding the
@@ -1736,7 +1748,7 @@ static_assert(NUM_PANEL_FIT * 4 <= NUM_PANEL_SLOTS * 3, "a stretch fills the tab
 // (masked out) find their bit clear and are dropped, so the mask is not consulted.  The panel leaves vals in
 // index order: Cx and Ci are straight copies.  Wider (sparser) stretches are hashed as before; the two table
 // layouts share the same LDS and are re-initialised when the kind of panel changes.
-static constexpr int RANK_WORDS = 5888;                               // 46 KiB of LDS
+static constexpr int RANK_WORDS = 23 * PANEL_THREADS / 4;                               // 46 KiB of LDS
 static constexpr int RANK_PPT = 6;                                    // pairs per thread: a ranked stretch has at most RANK_WORDS + 1
 static_assert(RANK_PPT * PANEL_THREADS > RANK_WORDS, "all pairs of a ranked stretch are held at once");
 static_assert((int64_t)RANK_WORDS * 32 <= PANEL_MAX_WIDTH, "ranked panel too wide for 32-bit product offsets");
@@ -2171,7 +2183,7 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
     GBA_HIP(hipGetLastError());
     mark(3);
     if (nb.count[BIN_GLOBAL] > 0 && P.use_panels && P.maxdeg < PANEL_MAX_DEG) {
-        int64_t nblocks = (int64_t)ctx().num_cu;
+        int64_t nblocks = (int64_t)ctx().num_cu * PANEL_WG_PER_CU;
         if (nblocks > nb.count[BIN_GLOBAL]) nblocks = nb.count[BIN_GLOBAL];
         // tasks: heaviest first, hub vectors cut at recorded boundaries
         const int64_t nl = nb.count[BIN_GLOBAL];
@@ -2268,7 +2280,7 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
     }
     GBA_HIP(hipGetLastError());
     if (sb.count[BIN_GLOBAL] > 0 && P.use_panels && P.maxdeg < PANEL_MAX_DEG) {
-        int64_t nblocks = (int64_t)ctx().num_cu;
+        int64_t nblocks = (int64_t)ctx().num_cu * PANEL_WG_PER_CU;
         if (nblocks > sb.count[BIN_GLOBAL]) nblocks = sb.count[BIN_GLOBAL];
         DevBuf scratch, next;
         GBA_OK(scratch.alloc((size_t)nblocks * PANEL_SCRATCH_ARRAYS * (size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
