@@ -243,7 +243,13 @@ dot3_wave_kernel(S sr, Dot3Mask M, const int64_t *__restrict__ Jof, OperandView 
 // vector take the serial dot product of dot_serial, or go to the long list of dot3_wave_kernel, as the work estimate
 // of Source/Template/GB_AxB_dot3_phase1_template.c:97-125 says.
 constexpr int D3_THREADS = 1024;            // threads of a workgroup = mask entries of a chunk
-constexpr int D3_SLOTS = 16384;             // slots of the LDS hash set
+#ifndef GBA_D3_SLOTS
+#define GBA_D3_SLOTS 16384
+#endif
+#ifndef GBA_D3_WGS
+#define GBA_D3_WGS 1
+#endif
+constexpr int D3_SLOTS = GBA_D3_SLOTS;       // slots of the LDS hash set
 constexpr int D3_SEG = D3_SLOTS / 2;        // keys of B(:,j) staged at a time
 constexpr int D3_HEAVY = 64;                // shortest B(:,j) worth staging
 constexpr int D3_SMALL = 16;                // longest A(:,i) one thread walks alone
@@ -269,7 +275,7 @@ static size_t dot3_team_lds_bytes(size_t zsize) {
 }
 
 template <class S>
-__global__ void __launch_bounds__(D3_THREADS)
+__global__ void __launch_bounds__(D3_THREADS, GBA_D3_WGS)
 dot3_team_kernel(S sr, int64_t mnz, Dot3Mask M, const int64_t *__restrict__ Jof, OperandView A, OperandView B,
                  int64_t long_work, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx,
                  unsigned long long *__restrict__ nzombies, unsigned int *__restrict__ nlong,
