@@ -1908,13 +1908,17 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
 #pragma unroll
                     for (int u = 0; u < NUM_PANEL_UNROLL; u++) t[u] = sr.mult(r[u].a, r[u].b, (int64_t)i[u], r[u].k, j);
                     if (ranked) {
+                        uint2 w[NUM_PANEL_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < NUM_PANEL_UNROLL; u++) {                   // all table reads of the window together
+                            const uint32_t wd = ((uint32_t)i[u] >> 5) - wbase32;       // the table is aligned to whole words
+                            w[u] = rk[ok[u] ? wd : 0u];
+                        }
 #pragma unroll
                         for (int u = 0; u < NUM_PANEL_UNROLL; u++) {
-                            const uint32_t wd = ((uint32_t)i[u] >> 5) - wbase32;       // the table is aligned to whole words
-                            const uint2 w = rk[ok[u] ? wd : 0u];
                             const uint32_t bit = 1u << ((uint32_t)i[u] & 31u);
-                            if (ok[u] && (w.x & bit)) {
-                                const uint32_t slot = w.y + (uint32_t)__builtin_popcount(w.x & (bit - 1u));
+                            if (ok[u] && (w[u].x & bit)) {
+                                const uint32_t slot = w[u].y + (uint32_t)__builtin_popcount(w[u].x & (bit - 1u));
                                 ridx[slot] = i[u];
                                 sr.atomic(&vals[slot], t[u]);
                             }
@@ -1975,8 +1979,8 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                 // in index order: Cx and Ci are straight copies; leave the table clean
                 Z *__restrict__ cx = Cx + pC;
                 int64_t *__restrict__ ci = Ci + pC;
-                for (int s = tid; s < rtotal; s += PANEL_THREADS) { cx[s] = (Z)vals[s]; ci[s] = (int64_t)ridx[s]; vals[s] = ident; }
                 const int nw = (int)(((lim - 1) >> 5) - (base >> 5)) + 1;
+                for (int s = tid; s < rtotal; s += PANEL_THREADS) { cx[s] = (Z)vals[s]; ci[s] = (int64_t)ridx[s]; vals[s] = ident; }
                 for (int s = tid; s < nw; s += PANEL_THREADS) rk[s] = make_uint2(0u, 0u);
             } else {
                 // emit the panel (wave-aggregated positions, coalesced stores) and leave the table clean
