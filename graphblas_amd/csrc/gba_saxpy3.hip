@@ -990,6 +990,9 @@ team_gather_kernel(int64_t nf, const uint64_t *__restrict__ Hf, const typename S
 // into A(:,k), the index stored at the cursor, and the end of A(:,k).  A
 // neighbour with nothing inside the panel is dismissed from those coalesced
 // arrays alone, without touching A.
+#ifndef GBA_TABLE_MAX_DEG
+#define GBA_TABLE_MAX_DEG 512
+#endif
 #ifdef GBA_PANEL_HALF
 static constexpr int PANEL_THREADS = 512;
 static constexpr int PANEL_WG_PER_CU = 2;
@@ -1363,6 +1366,60 @@ __device__ inline void panel_walk_groups(const SpView &A, const SpView &B, int64
     const int ns = S->nseg;
     if (ns > 0) panel_expand<PANEL_UNROLL, PANEL_PIPELINE>(A, pB0, ns, S, load, apply, take_turns);
     else __syncthreads();
+}
+
+// panel_walk for the numeric sweep of a vector whose panel boundaries are known in advance
+// (recorded by the symbolic sweep): where every neighbour's list crosses every boundary of the task was looked up
+// once, when the task started (tab[m * deg + t] = first position of neighbour t at or after boundary m; row nrows-1
+// = end of the task's range), so a panel that runs from boundary row_lo to boundary row_hi reads its runs from two
+// rows of that table instead of searching.  A panel that does not start or end on a boundary (after an overflow, or
+// a directly addressed panel) passes -1 for that row and the position is found by bisection inside the task's
+// range.  No cursors are kept.  Same barriers, the same queue handling and the same S->more contract as panel_walk.
+template <int PANEL_UNROLL, bool PANEL_PIPELINE, class Load, class Apply>
+__device__ inline void panel_walk_table(const SpView &A, int64_t pB0, int64_t deg, int64_t base, int64_t pend,
+                                        const int64_t *__restrict__ tab, int nrows, int row_lo, int row_hi,
+                                        PanelSegs *S, Load load, Apply apply, bool take_turns) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int32_t *__restrict__ Ai = A.i32;
+    for (int64_t t0 = 0; t0 < deg; t0 += PANEL_THREADS) {
+        GBA_TICK(tk0);
+        const int64_t t = t0 + tid;
+        const bool live = t < deg;
+        int64_t lo = 0, hi = 0;
+        if (live) {
+            const int64_t first = tab[t], last = tab[(int64_t)(nrows - 1) * deg + t];
+            if (row_lo >= 0) lo = tab[(int64_t)row_lo * deg + t];
+            else { int64_t a = first, b = last; while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)Ai[m] < base) a = m + 1; else b = m; } lo = a; }
+            if (row_hi >= 0) hi = tab[(int64_t)row_hi * deg + t];
+            else if (pend >= PANEL_INF) hi = last;
+            else { int64_t a = lo, b = last; while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)Ai[m] < pend) a = m + 1; else b = m; } hi = a; }
+            if (hi < last) S->more = 1;
+        }
+        const bool has = live && hi > lo;
+        const unsigned long long m = __ballot(has);
+        if (m) {
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(&S->nseg, (int)__builtin_popcountll(m));
+            slot = __shfl(slot, 0, 64);
+            if (has) {
+                slot += (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                S->where[slot] = ((unsigned long long)lo << PANEL_T_BITS) | (unsigned long long)t;
+                S->off[slot] = (uint32_t)(hi - lo);
+            }
+        }
+        GBA_TICK(tk1);
+        __syncthreads();
+        GBA_TICK(tk2);
+        GBA_TOCK(S, 0, tk0, tk1); GBA_TOCK(S, 1, tk1, tk2);
+        const int ns = S->nseg;
+        const bool last_step = t0 + PANEL_THREADS >= deg;
+        if (ns > 0 && (ns > PANEL_SEGCAP - PANEL_THREADS || last_step)) {
+            panel_expand<PANEL_UNROLL, PANEL_PIPELINE>(A, pB0, ns, S, load, apply, take_turns);
+            if (S->overflow) return;
+        } else {
+            __syncthreads();                                    // everyone has read nseg before the next append
+        }
+    }
 }
 
 // Visit the products A(i,k)*B(k,j) with ibeg <= i < pend that have not been
@@ -1762,7 +1819,7 @@ template <class ACC> constexpr size_t num_panel_lds() {
 template <class S, bool MASKED>
 __global__ void __launch_bounds__(PANEL_THREADS)
 num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpView A, SpView B, MaskView M, int64_t cvlen,
-                 int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
+                 int64_t maxdeg, int64_t scratch_stride, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
                  const int64_t *__restrict__ Cp, int64_t *__restrict__ Ci, typename S::z_t *__restrict__ Cx,
                  const int64_t *__restrict__ bstart, const int64_t *__restrict__ bounds,
                  const int64_t *__restrict__ pstart, const uint2 *__restrict__ pwords, const int64_t *__restrict__ wbounds,
@@ -1781,7 +1838,8 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
     const ACC ident = (ACC)sr.identity();
     const bool apat = sr.a_is_pattern(), bpat = sr.b_is_pattern();
     const int tid = threadIdx.x, lane64 = tid & 63;
-    PanelCursors pc(scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg, maxdeg);
+    int64_t *__restrict__ my_scratch = scratch + (int64_t)blockIdx.x * scratch_stride;
+    PanelCursors pc(my_scratch, maxdeg);
     for (int s = tid; s < NUM_PANEL_SLOTS; s += PANEL_THREADS) { keys[s] = HASH_EMPTY; vals[s] = ident; }
     bool rank_layout = false;                               // which of the two layouts the LDS holds, clean
     if (tid == 0) Q.nseg = 0;
@@ -1826,6 +1884,48 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
         }
         const int64_t ibeg = base;
         int64_t shrink = 0;                             // halvings after an overflow (never needed with boundaries)
+        // Boundaries on record and room for the table: where every neighbour's list crosses every boundary of the task is
+        // looked up once, here, and the panels read their runs from that table (panel_walk_table) instead of
+        // searching panel after panel.  Rows: boundary q0 (the task's first index) .. boundary q0 + nrows - 1 (its end).
+        const int64_t q0 = task.q0;
+        const int nrows = jb ? (int)(((task.q1 <= nb) ? task.q1 : nb + 1) - q0) + 1 : 0;
+        const bool by_table = jb && deg <= GBA_TABLE_MAX_DEG && nrows >= 2 && (int64_t)nrows * deg <= scratch_stride
+#ifdef GBA_PANEL_NO_TABLE
+                              && false
+#endif
+                              ;
+        if (by_table) {
+            // first the two ends of every neighbour's range inside the task, then every boundary in between by a
+            // bisection of its own inside that range: independent searches, all threads busy
+            const int32_t *__restrict__ Ai = A.i32;
+            int64_t *__restrict__ row_first = my_scratch, *__restrict__ row_last = my_scratch + (int64_t)(nrows - 1) * deg;
+            const int64_t q_last = q0 + nrows - 1;
+            for (int64_t t = tid; t < deg; t += PANEL_THREADS) {
+                const int64_t k = B.i[pB0 + t];
+                int64_t a = A.p[k], b = A.p[k + 1];
+                if (q0 > 0) {
+                    const int64_t v = jb[q0 - 1];
+                    int64_t hi = b;
+                    while (a < hi) { const int64_t mid = (a + hi) >> 1; if ((int64_t)Ai[mid] < v) a = mid + 1; else hi = mid; }
+                }
+                if (q_last <= nb) {
+                    const int64_t v = jb[q_last - 1];
+                    int64_t lo = a;
+                    while (lo < b) { const int64_t mid = (lo + b) >> 1; if ((int64_t)Ai[mid] < v) lo = mid + 1; else b = mid; }
+                }
+                row_first[t] = a; row_last[t] = b;
+            }
+            __syncthreads();
+            const int64_t cells = (int64_t)(nrows - 2) * deg;               // rows 1 .. nrows - 2
+            for (int64_t idx = tid; idx < cells; idx += PANEL_THREADS) {
+                const int64_t m = (int64_t)((uint32_t)idx / (uint32_t)deg), t = idx - m * deg;     // (cells < 2^27)
+                int64_t a = row_first[t], b = row_last[t];
+                const int64_t v = jb[q0 + m];                              // boundary q0 + m + 1
+                while (a < b) { const int64_t mid = (a + b) >> 1; if ((int64_t)Ai[mid] < v) a = mid + 1; else b = mid; }
+                my_scratch[(m + 1) * deg + t] = a;
+            }
+            __syncthreads();
+        }
         while (true) {
             if (jb) {
                 while (mb < nb && jb[mb] <= base) mb++;
@@ -1899,11 +1999,14 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                     rank += (uint32_t)__builtin_popcount(pbit[q]);
                 }
             }                                           // (the barrier after the search stands between this and the products)
-            panel_walk<NUM_PANEL_UNROLL, NUM_PANEL_PIPELINE>(A, B, pB0, deg, ibeg, pend, iend, first, pc, &Q,
-                [&](int32_t, int64_t pA, int64_t pB) -> PanelOperands<S> {
+            // (by_table) the rows of the table this panel starts and ends on, -1 where it does not stand on a boundary
+            const int row_lo = (by_table && base == ((mb > 0) ? jb[mb - 1] : 0)) ? (int)(mb - q0) : -1;
+            const int row_hi = (by_table && lim == ((mb < nb) ? jb[mb] : cvlen) && mb + 1 - q0 < nrows) ? (int)(mb + 1 - q0)
+                             : (by_table && lim == iend && iend < PANEL_INF) ? nrows - 1 : -1;
+            auto load_operands = [&](int32_t, int64_t pA, int64_t pB) -> PanelOperands<S> {
                     return fetch_operands(sr, A, B, apat, bpat, pA, pB);
-                },
-                [&](const int32_t (&i)[NUM_PANEL_UNROLL], const PanelOperands<S> (&r)[NUM_PANEL_UNROLL], const bool (&ok)[NUM_PANEL_UNROLL]) {
+                };
+            auto apply_products = [&](const int32_t (&i)[NUM_PANEL_UNROLL], const PanelOperands<S> (&r)[NUM_PANEL_UNROLL], const bool (&ok)[NUM_PANEL_UNROLL]) {
                     Z t[NUM_PANEL_UNROLL];
 #pragma unroll
                     for (int u = 0; u < NUM_PANEL_UNROLL; u++) t[u] = sr.mult(r[u].a, r[u].b, (int64_t)i[u], r[u].k, j);
@@ -1965,7 +2068,13 @@ num_panel_kernel(S sr, int64_t nlist, const PanelTask *__restrict__ tasks, SpVie
                         }
                         if (slot >= 0) sr.atomic(&vals[slot], t[u]); else Q.overflow = 1;
                     }
-                }, true);
+                };
+            if (by_table)
+                panel_walk_table<NUM_PANEL_UNROLL, NUM_PANEL_PIPELINE>(A, pB0, deg, base, pend, my_scratch, nrows, row_lo, row_hi, &Q,
+                                                                        load_operands, apply_products, true);
+            else
+                panel_walk<NUM_PANEL_UNROLL, NUM_PANEL_PIPELINE>(A, B, pB0, deg, ibeg, pend, iend, first, pc, &Q,
+                                                                  load_operands, apply_products, true);
             if (!ranked && Q.overflow) {                 // uniform: raised before the barrier that ended the walk
                 width = (width > 1) ? (width >> 1) : 1;
                 shrink++;
@@ -2207,14 +2316,17 @@ static gba_info run_numeric(const S &sr, Saxpy3Plan &P) {
         GBA_HIP(hipGetLastError());
         if (nblocks > ntasks) nblocks = ntasks;
         DevBuf scratch, next;
-        GBA_OK(scratch.alloc((size_t)nblocks * PANEL_SCRATCH_ARRAYS * (size_t)(P.maxdeg > 0 ? P.maxdeg : 1) * 8));
+        // per workgroup: the cursor arrays of panel_walk, or the boundary table of panel_walk_table (at least 2^20 cells)
+        int64_t scratch_stride = (int64_t)PANEL_SCRATCH_ARRAYS * (P.maxdeg > 0 ? P.maxdeg : 1);
+        if (scratch_stride < ((int64_t)1 << 20)) scratch_stride = (int64_t)1 << 20;
+        GBA_OK(scratch.alloc((size_t)nblocks * (size_t)scratch_stride * 8));
         GBA_OK(next.alloc(128));
         GBA_HIP(hipMemsetAsync(next.p, 0, 128, st));
         auto k = (P.M.kind == 0) ? num_panel_kernel<S, false> : num_panel_kernel<S, true>;
         const size_t lds = num_panel_lds<ACC>();
         GBA_OK(set_lds(k, lds));
         hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
-                           sr, ntasks, tasks.as<PanelTask>(), P.A, P.B, P.M, P.cvlen, P.maxdeg,
+                           sr, ntasks, tasks.as<PanelTask>(), P.A, P.B, P.M, P.cvlen, P.maxdeg, scratch_stride,
                            scratch.as<int64_t>(), next.as<unsigned long long>(), P.Cp, P.Ci, Cx, P.bstart, P.bounds,
                            P.pstart, P.pwords, P.wbounds, P.vflops);
         GBA_HIP(hipGetLastError());
