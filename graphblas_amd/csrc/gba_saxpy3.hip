@@ -1642,13 +1642,38 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
         uint2 *pw = pwords ? pwords + pstart[j] : nullptr;  // where the non-empty bitmap words of C(:,j) are written, in index order
         int64_t *jw = pwords ? wbounds + bstart[j] : nullptr;   // and where the word of every boundary stands in that list
         int64_t seen = 0, wseen = 0;                        // entries / non-empty words of C(:,j) below the current panel
+        // Few neighbours: where every neighbour's list crosses the panel edges (multiples of the panel width) is
+        // looked up once, by independent bisections, and the sweeps read their runs from that table
+        // (panel_walk_table) instead of advancing cursors with the group search.
+        const bool by_table = deg * 2 <= PANEL_THREADS && (npanels + 1) * deg <= (int64_t)PANEL_SCRATCH_ARRAYS * maxdeg
+#ifdef GBA_PANEL_NO_SYM_TABLE
+                              && false
+#endif
+                              ;
+        int64_t *__restrict__ my_scratch = scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg;
+        if (by_table) {
+            const int32_t *__restrict__ Ai = A.i32;
+            const int64_t cells = (npanels + 1) * deg;
+            for (int64_t idx = tid; idx < cells; idx += PANEL_THREADS) {
+                const int64_t m = (int64_t)((uint32_t)idx / (uint32_t)deg), t = idx - m * deg;
+                const int64_t k = B.i[pB0 + t];
+                int64_t a = A.p[k], b = A.p[k + 1];
+                if (m == npanels) a = b;
+                else if (m > 0) {
+                    const int64_t v = m * SYM_PANEL_WIDTH;
+                    while (a < b) { const int64_t mid = (a + b) >> 1; if ((int64_t)Ai[mid] < v) a = mid + 1; else b = mid; }
+                }
+                my_scratch[idx] = a;
+            }
+            __syncthreads();
+        }
         for (int64_t p = 0; p < npanels; p++) {
             const int64_t base = p * SYM_PANEL_WIDTH;
             const int64_t pend = (p == npanels - 1) ? PANEL_INF : base + SYM_PANEL_WIDTH;
             if (tid == 0) Q.more = 0;
             __syncthreads();
-            panel_walk<SYM_PANEL_UNROLL, SYM_PANEL_PIPELINE>(A, B, pB0, deg, 0, pend, PANEL_INF, p == 0, pc, &Q,
-                [](int32_t, int64_t, int64_t) { return 0; },
+            auto no_load = [](int32_t, int64_t, int64_t) { return 0; };
+            auto mark_products =
                 [&](const int32_t (&i)[SYM_PANEL_UNROLL], const int (&)[SYM_PANEL_UNROLL], const bool (&ok)[SYM_PANEL_UNROLL]) {
 #pragma unroll
                     for (int u = 0; u < SYM_PANEL_UNROLL; u++) {
@@ -1657,7 +1682,12 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                         const uint32_t o = (uint32_t)(i[u] - base);
                         atomicOr(&bm[(o >> 5) + (o >> 10)], 1u << (o & 31));     // (word o >> 5, in slice o >> 10)
                     }
-                }, false);
+                };
+            if (by_table)
+                panel_walk_table<SYM_PANEL_UNROLL, SYM_PANEL_PIPELINE>(A, pB0, deg, base, pend, my_scratch, (int)npanels + 1, (int)p, (int)p + 1,
+                                                                        &Q, no_load, mark_products, false);
+            else
+                panel_walk<SYM_PANEL_UNROLL, SYM_PANEL_PIPELINE>(A, B, pB0, deg, 0, pend, PANEL_INF, p == 0, pc, &Q, no_load, mark_products, false);
             // count in index order: each thread owns SYM_WORDS_PER_THREAD consecutive words (its slice); the packed
             // sum carries the entries (low 21 bits: a panel has at most 2^20) and the non-empty words (above)
             const int w0 = tid * SYM_WORDS_PER_THREAD;
