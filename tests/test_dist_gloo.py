@@ -227,3 +227,34 @@ def test_two_ranks_count_the_triangles_of_the_whole_graph(tmp_path):
     got = [np.load(tmp_path / f"t{r}.npz") for r in range(world)]
     assert all(int(g["total"]) == want for g in got)
     assert sum(int(g["mine"]) for g in got) == want and all(int(g["mine"]) > 0 for g in got)
+
+
+def _worker_uneven(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from graphblas_amd.dist import all_gather_in_place, FrontierExchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    counts = [5, 0, 3]
+    offs = [0, 5, 5]
+    mine = torch.arange(counts[rank], dtype=torch.int64) + 100 * rank
+    out = torch.full((8,), -1, dtype=torch.int64)
+    all_gather_in_place(dist, torch, mine, out, offs, counts, rank)
+    fx = FrontierExchange(dist, torch, rank, world, torch.device("cpu"))
+    gi, gv = fx.sparse(mine, mine.to(torch.float64) * 0.5)
+    np.savez(os.path.join(outdir, f"u{rank}.npz"), out=out.numpy(), gi=gi.numpy(), gv=gv.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pieces_of_unequal_length_land_in_place_on_three_ranks(tmp_path):
+    """The exact-size all-gather with an empty piece in the middle: every rank ends with the concatenation, nothing
+    is padded, and the frontier exchange built on it returns the same lists everywhere."""
+    import torch.multiprocessing as mp
+    world, port = 3, 35500 + (os.getpid() % 2000)
+    mp.spawn(_worker_uneven, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    want = np.array([0, 1, 2, 3, 4, 200, 201, 202], np.int64)
+    for r in range(world):
+        got = np.load(tmp_path / f"u{r}.npz")
+        assert np.array_equal(got["out"], want)
+        assert np.array_equal(got["gi"], want) and np.array_equal(got["gv"], want * 0.5)
