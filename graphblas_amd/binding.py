@@ -82,7 +82,7 @@ class gba_matrix(C.Structure):
         ("vlen", C.c_int64), ("vdim", C.c_int64), ("nvec", C.c_int64), ("nvals", C.c_int64),
         ("p", C.c_void_p), ("h", C.c_void_p), ("i", C.c_void_p), ("x", C.c_void_p), ("b", C.c_void_p),
         ("nzombies", C.c_int64), ("type", C.c_int32), ("sparsity", C.c_int32), ("mem", C.c_int32),
-        ("is_csc", C.c_bool), ("iso", C.c_bool), ("jumbled", C.c_bool),
+        ("is_csc", C.c_bool), ("iso", C.c_bool), ("jumbled", C.c_bool), ("hyper_switch", C.c_float),
     ]
 
 

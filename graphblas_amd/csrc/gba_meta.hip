@@ -1256,9 +1256,23 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
         return mxm_complex(k.C, k.M, k.has_accum ? &k.accum : nullptr, &k.semiring, k.A_in, k.A_transpose, k.B_in,
                            k.B_transpose, k.flipxy, k.C_replace, k.Mask_comp, k.Mask_struct, report);
     const bool C_was_hyper = k.C && is_hyper(k.C);
+    const float hs = k.C ? k.C->hyper_switch : 0.0f;         // (a result that replaces C brings its own, zeroed, fields)
     const gba_info info = mxm_driver_sparse_C(k, report, select_only);
-    if (!C_was_hyper || select_only || !is_sparse(k.C) || k.C->mem != GBA_MEM_DEVICE) return info;
-    if (info == GBA_SUCCESS) return sparse_to_hyper(k.C);
+    if (k.C) k.C->hyper_switch = hs;
+    if (select_only || !k.C || !is_sparse(k.C) || k.C->mem != GBA_MEM_DEVICE) return info;
+    if (info == GBA_SUCCESS) {
+        // the form of a sparse result: as it came in, or by the reference's hyper_switch rule when C carries one
+        bool to_hyper = C_was_hyper;
+        if (hs > 0.0f) {
+            int64_t nonempty = 0;
+            GBA_OK(nonempty_vectors(k.C, &nonempty));
+            const float n = (float)k.C->vdim;
+            to_hyper = C_was_hyper ? !(n <= 1.0f || (float)nonempty > n * hs * 2.0f)       // GB_convert_hyper_to_sparse_test.c
+                                   : (n > 1.0f && (float)nonempty <= n * hs);               // GB_convert_sparse_to_hyper_test.c
+        }
+        return to_hyper ? sparse_to_hyper(k.C) : GBA_SUCCESS;
+    }
+    if (!C_was_hyper) return info;
     // A call that failed or was declined after C had been expanded hands C back as it came: hypersparse, with the
     // same vectors and entries (a caller that falls back to the CPU library finds its C untouched).  The message of
     // the failure is kept.

@@ -485,6 +485,21 @@ hyper_gather_kernel(int64_t nvec, const int64_t *__restrict__ p, const int64_t *
         if (p[j + 1] > p[j]) { h[pos[j]] = j; hp[pos[j]] = p[j]; }
 }
 
+// number of non-empty vectors of a sparse or hypersparse matrix on the device
+gba_info nonempty_vectors(const gba_matrix *C, int64_t *k) {
+    GBA_OK(require_init());
+    hipStream_t st = ctx().stream;
+    const int64_t nvec = C->nvec;
+    *k = 0;
+    if (nvec <= 0) return GBA_SUCCESS;
+    DevBuf flag;
+    GBA_OK(flag.alloc((size_t)(nvec + 1) * 8));
+    int64_t blocks = ceil_div(nvec, 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(hyper_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, C->p, flag.as<int64_t>());
+    GBA_OK(dev_cumsum_i64(flag.as<int64_t>(), nvec, st));
+    return dev_read_i64(flag.as<int64_t>() + nvec, k);
+}
+
 gba_info sparse_to_hyper(gba_matrix *C) {
     GBA_OK(require_init());
     if (!is_sparse(C) || C->mem != GBA_MEM_DEVICE) GBA_FAIL(GBA_INVALID_VALUE, "sparse_to_hyper: sparsity %d", C->sparsity);

@@ -127,6 +127,13 @@ typedef struct gba_matrix {
     bool     is_csc;
     bool     iso;
     bool     jumbled;    /* indices within a vector may be out of order */
+    float    hyper_switch;  /* of an OUTPUT of gba_mxm / gba_mxv / gba_vxm: when > 0, a sparse or hypersparse result is
+                               re-conformed as the reference does at the end of GB_mxm (Source/GB_conform_hyper.c): to
+                               hypersparse when vdim > 1 and its non-empty vectors are at most hyper_switch * vdim
+                               (GB_convert_sparse_to_hyper_test.c), back to sparse when vdim <= 1 or they are more than
+                               2 * hyper_switch * vdim (GB_convert_hyper_to_sparse_test.c).  The reference's default is
+                               0.0625 (GxB_HYPER_DEFAULT).  0 (a zeroed struct) or negative: the result keeps the form it
+                               came in with (sparse stays sparse, hypersparse stays hypersparse).  Ignored for inputs. */
 } gba_matrix;
 
 #define GBA_FLIP(i) (-(i) - 2)          /* Source/Template/GB_zombie.h */

@@ -472,6 +472,12 @@ static bool shim_run (int which, shim_call *k, const GrB_BinaryOp accum,
     if (!shim_device_ready ()) return (false) ;
     gba_matrix cdev ;
     if (k->c->v.iso || !shim_upload (&cdev, &(k->c->v), 0)) return (false) ;
+    if (k->c->A != NULL)
+    {
+        /* the result is re-conformed to sparse or hypersparse by C's own hyper_switch, as GB_mxm ends (GB_conform) */
+        double hs = 0 ;
+        if (GxB_Matrix_Option_get (k->c->A, GxB_HYPER_SWITCH, &hs) == GrB_SUCCESS && hs > 0) cdev.hyper_switch = (float) hs ;
+    }
     /* the inputs stay host views (an input that is also the output is read as it was on entry); C is cdev */
     const gba_matrix *m = k->has_mask ? &(k->m->v) : NULL ;
     gba_info info ;

@@ -30,6 +30,7 @@ struct GB_Matrix_opaque
     bool by_row, iso, jumbled, held ;
     GrB_Index *p, *h, *i ; void *x ; int8_t *b ;
     GrB_Index p_size, h_size, i_size, x_size, b_size, nvals, nvec ;
+    double hyper_switch ;       /* 0 in a fresh handle of this double (the library's own default is 0.0625) */
 } ;
 struct GB_Vector_opaque
 {
@@ -125,6 +126,7 @@ GrB_Info GxB_Matrix_Option_get (GrB_Matrix A, GxB_Option_Field field, ...)
     GrB_Info info = GrB_SUCCESS ;
     if (field == GxB_SPARSITY_STATUS) { int *s = va_arg (ap, int *) ; (*s) = A->sparsity ; }
     else if (field == GxB_FORMAT) { GxB_Format_Value *f = va_arg (ap, GxB_Format_Value *) ; (*f) = A->by_row ? GxB_BY_ROW : GxB_BY_COL ; }
+    else if (field == GxB_HYPER_SWITCH) { double *h = va_arg (ap, double *) ; (*h) = A->hyper_switch ; }
     else info = GrB_INVALID_VALUE ;
     va_end (ap) ;
     return (info) ;
@@ -514,3 +516,6 @@ void fake_vector_free (GrB_Vector v)
     if (v == NULL) return ;
     fk_free (v->i) ; fk_free (v->x) ; fk_free (v->b) ; free (v) ;
 }
+
+/* test helper: the hyper_switch of a handle (GxB_Matrix_Option_set (A, GxB_HYPER_SWITCH, h) in the real library) */
+void fake_matrix_set_hyper_switch (GrB_Matrix A, double h) { A->hyper_switch = h ; }

@@ -473,3 +473,36 @@ def test_an_iso_valued_C_comes_in(gba, ckind, accum, masked):
     for d in (dA, dB, dC, dM):
         if d is not None:
             d.free()
+
+
+def test_hyper_switch_conforms_the_result(gba):
+    """The reference ends GB_mxm by re-conforming C (Source/GB_conform_hyper.c): sparse -> hypersparse when the
+    non-empty vectors are at most hyper_switch * vdim, hypersparse -> sparse when they are more than twice that.  A C
+    that carries no hyper_switch keeps the form it came in with."""
+    n = 400
+    rng = np.random.default_rng(5)
+    few = np.zeros((n, n)); few[:, [7, 90, 301]] = (rng.random((n, 3)) < 0.2) * rng.integers(1, 5, (n, 3))
+    B_few = Matrix.from_scipy(sp.csc_matrix(few), type=Type.FP64, by_row=False)          # three non-empty columns
+    A, B_many = _rand(n, n, 0.05, 51), _rand(n, n, 0.05, 52)
+    dA, dBf, dBm = A.to_device(), B_few.to_device(), B_many.to_device()
+
+    def product(dB, B, C0, switch):
+        dC = C0.to_device()
+        dC.view.hyper_switch = switch
+        gba.mxm(dC, None, None, "PLUS_TIMES_FP64", dA, dB, "")
+        got = dC.to_host()
+        p, v = oracle.mxm_spec(Matrix.sparse_empty(n, n, Type.FP64, by_row=False), None, None, "PLUS_TIMES_FP64", A, B, "")
+        assert_dense_same(got, p, v, exact=True, what=f"hyper_switch {switch}")
+        dC.free()
+        return got
+
+    empty = Matrix.sparse_empty(n, n, Type.FP64, by_row=False)
+    got = product(dBf, B_few, empty, 0.0625)
+    assert got.sparsity == Sparsity.HYPERSPARSE and list(got.h) == [7, 90, 301]          # 3 <= 0.0625 * 400
+    assert product(dBf, B_few, empty, 0.0).sparsity == Sparsity.SPARSE                   # never asked for
+    assert product(dBm, B_many, empty, 0.0625).sparsity == Sparsity.SPARSE               # 400 non-empty vectors
+    assert product(dBm, B_many, empty.to_hyper(), 0.0625).sparsity == Sparsity.SPARSE    # came in hypersparse: more than 2 * 25
+    assert product(dBm, B_many, empty.to_hyper(), 0.0).sparsity == Sparsity.HYPERSPARSE  # keeps the form it came in with
+    assert product(dBf, B_few, empty.to_hyper(), 0.0625).sparsity == Sparsity.HYPERSPARSE
+    for d in (dA, dBf, dBm):
+        d.free()

@@ -93,7 +93,13 @@ def look(fake, h, code, vector=False):
         return out
     if sparsity in (SPARSE, HYPER):
         nv = nrows if by_row else ncols
-        p = arr(0, nv + 1, np.int64)
+        if sparsity == HYPER:                                   # the listed vectors only: spread them out again
+            hp, hh = arr(0, nvec + 1, np.int64), arr(1, nvec, np.int64)
+            counts = np.zeros(nv, np.int64); counts[hh] = np.diff(hp)
+            p = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            out["h"] = hh
+        else:
+            p = arr(0, nv + 1, np.int64)
         i, x = arr(2, int(p[-1]), np.int64), arr(3, int(p[-1]), dt)
         M = (sp.csr_matrix if by_row else sp.csc_matrix)((x, i, p), shape=(nrows, ncols))
         M.sort_indices()
@@ -262,3 +268,33 @@ def test_pagerank_step_on_arrays_of_the_device_visible_allocator(libs, gba):
     finally:
         libc = C.CDLL(None)
         fake.fake_set_allocator(*[C.cast(getattr(libc, n), C.c_void_p) for n in ("malloc", "calloc", "realloc", "free")])
+
+
+@pytest.mark.parametrize("switch,want", [(0.0625, "hyper"), (0.0, "sparse")])
+def test_the_result_is_conformed_by_the_hyper_switch_of_C(libs, switch, want):
+    """C = A*A where only four of 256 rows of the result hold entries: with C's hyper_switch at the library's default
+    the handle comes back hypersparse (non-empty vectors <= hyper_switch * vdim, Source/GB_conform_hyper.c), with 0
+    (never asked for) it stays sparse; the entries are the same."""
+    shim, fake = libs
+    n = 256
+    rng = np.random.default_rng(8)
+    D = np.zeros((n, n))
+    for r in (3, 77, 130, 250):
+        D[r, rng.choice(n, 12, replace=False)] = rng.integers(1, 5, 12)
+    S = sp.csr_matrix(D)
+    A = make_csr(fake, S, FP64)
+    Cm = empty_matrix(fake, n, n, FP64)
+    fake.fake_matrix_set_hyper_switch.argtypes = [C.c_void_p, C.c_double]
+    fake.fake_matrix_set_hyper_switch(Cm, switch)
+    before = fake.fake_cpu_calls(0)
+    assert shim.GrB_mxm(Cm, None, None, obj(fake, "GrB_PLUS_TIMES_SEMIRING_FP64"), A, A, None) == 0
+    assert fake.fake_cpu_calls(0) == before
+    got = look(fake, Cm, FP64)
+    prod = (S @ S).tocsr(); prod.sort_indices()
+    assert (got["S"] != prod).nnz == 0 and got["S"].nnz == prod.nnz
+    if want == "hyper":
+        assert got["sparsity"] == HYPER
+        assert np.array_equal(got["h"], np.flatnonzero(np.diff(prod.indptr)))
+    else:
+        assert got["sparsity"] == SPARSE
+    fake.fake_matrix_free(A); fake.fake_matrix_free(Cm)
