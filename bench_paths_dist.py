@@ -1,10 +1,11 @@
-"""The programs of bench_paths.py on N GPUs of one node: one process per GPU, every product sharded by row blocks of
-its OUTPUT, the exchanges of graphblas_amd.dist between the products.
+"""The programs of bench_paths.py on N GPUs of one node: one process per GPU, every product sharded by row blocks (of
+its output; of A and the frontier for the traversal), the exchanges of graphblas_amd.dist between the products.
 
   spmv      x <- A x / max|A x|   rank r computes y(I_r) = A(I_r,:) x (gba_mxv, dot4), the blocks are all-gathered into
                                   the next x (VectorBlockExchange); every rank then holds all of y and scales it itself
-  bfs       w(I_r)<!pi(I_r),struct,replace> = A(I_r,:) q with ANY_SECONDI_INT64 (gba_mxv: the pull form of the push
-            step q'A on a symmetric graph), the new frontier exchanged as index lists (FrontierExchange.sparse)
+  bfs       w_r<!pi,struct,replace> = q(I_r)' A(I_r,:) with ANY_SECONDI_INT64 (gba_vxm: the push step of the one-GPU
+            program on the rows of A this rank holds and its share of the frontier), the lists of vertices found
+            exchanged (FrontierExchange.sparse) and merged: a vertex reached from several blocks keeps one parent
   sssp      d(I_r) = min(d(I_r), A'(I_r,:) min.+ d) with MIN_PLUS_FP64 and the MIN accumulator (gba_mxv, dot4 in
             place), the blocks all-gathered (VectorBlockExchange)
   tricount  C(I_r,:)<L(I_r,:),struct> = L(I_r,:) L' with PLUS_PAIR_INT64 (gba_mxm, dot3) against the whole L, only the
@@ -181,42 +182,63 @@ def bfs(R, args):
         level_of = np.full(n, -1, np.int64); parent = np.full(n, -1, np.int64)
         level_of[src] = 0; parent[src] = src
         pi_b = np.zeros(n, np.int8); pi_b[src] = 1
-        q_idx = np.array([src], np.int64)
+        q_idx = np.array([src], np.int64)                            # the whole frontier, ascending, on every rank
         per_level = []
+        spent = {"product": 0.0, "exchange": 0.0}                    # inside gba_vxm / inside the exchange, this rank
         R.fence()
         t0 = time.perf_counter()
         for level in range(1, 64):
-            if len(q_idx) > n // 64:
-                b = np.zeros(n, np.int8); b[q_idx] = 1
-                q = Matrix.bitmap_vector(np.zeros(n, np.int64), b)
-            else:
-                q = Matrix.sparse_vector(n, q_idx, np.zeros(len(q_idx), np.int64))
-            dq = q.to_device()
-            dpi = Matrix.bitmap_vector(np.zeros(hi - lo, np.int64), pi_b[lo:hi]).to_device()
-            dw = Matrix.sparse_vector(hi - lo, [], np.zeros(0, np.int64)).to_device()
-            rep = g.mxv(dw, dpi, None, "ANY_SECONDI_INT64", dA, dq, "RSC")
-            w = dw.to_host()
-            for d in (dq, dpi, dw):
-                d.free()
-            r, _, par = w.coo()                                      # whatever form the method left w in
-            mine_i = torch.from_numpy(np.ascontiguousarray(r + lo)).to(R.dev)
-            mine_p = torch.from_numpy(np.ascontiguousarray(par)).to(R.dev)
-            gi, gp = fx.sparse(mine_i, mine_p)
-            found, parents = gi.cpu().numpy(), gp.cpu().numpy()
-            per_level.append(dict(level=level, frontier=int(len(q_idx)), found=int(len(found)), method=g.Method.NAMES[rep.method]))
+            # this rank's share of the frontier: the vertices whose rows of A it holds
+            a, b = np.searchsorted(q_idx, [lo, hi])
+            mine = q_idx[a:b] - lo
+            method = "none"
+            r = np.zeros(0, np.int64); par = np.zeros(0, np.int64)
+            if len(mine):
+                if len(mine) > (hi - lo) // 8:
+                    bq = np.zeros(hi - lo, np.int8); bq[mine] = 1
+                    q = Matrix.bitmap_vector(np.zeros(hi - lo, np.int64), bq)
+                else:
+                    q = Matrix.sparse_vector(hi - lo, mine, np.zeros(len(mine), np.int64))
+                dq = q.to_device()
+                dpi = Matrix.bitmap_vector(np.zeros(n, np.int64), pi_b).to_device()
+                dw = Matrix.sparse_vector(n, [], np.zeros(0, np.int64)).to_device()
+                g.sync()
+                tc = time.perf_counter()
+                rep = g.vxm(dw, dpi, None, "ANY_SECONDI_INT64", dq, dA, "RSC")     # w<!pi> = q(I)' A(I,:): SECONDI = row of the block
+                g.sync()
+                spent["product"] += time.perf_counter() - tc
+                w = dw.to_host()
+                for d in (dq, dpi, dw):
+                    d.free()
+                r, _, par = w.coo()                                  # whatever form the method left w in
+                par = par + lo
+                method = g.Method.NAMES[rep.method]
+            ti, tp = torch.from_numpy(np.ascontiguousarray(r)).to(R.dev), torch.from_numpy(np.ascontiguousarray(par)).to(R.dev)
+            torch.cuda.synchronize()
+            tx = time.perf_counter()
+            gi, gp = fx.sparse(ti, tp)
+            torch.cuda.synchronize()
+            spent["exchange"] += time.perf_counter() - tx
+            found, first = np.unique(gi.cpu().numpy(), return_index=True)   # a vertex reached from several blocks keeps one parent
+            parents = gp.cpu().numpy()[first]
+            per_level.append(dict(level=level, frontier=int(len(q_idx)), mine=int(len(mine)), found=int(len(found)), method=method))
             if len(found) == 0:
                 break
             level_of[found] = level; parent[found] = parents; pi_b[found] = 1
             q_idx = found
         R.fence()
-        return level_of, parent, per_level, R.max_over_ranks(time.perf_counter() - t0)
+        total = R.max_over_ranks(time.perf_counter() - t0)
+        return level_of, parent, per_level, (total, R.max_over_ranks(spent["product"]), R.max_over_ranks(spent["exchange"]))
 
     traverse()                                                      # loads the kernels, fills the memory pool
-    level_of, parent, per_level, sec = traverse()
+    level_of, parent, per_level, (sec, product_s, exchange_s) = traverse()
     dA.free()
-    rec = dict(case="BFS pull steps w(I)<!pi(I)> = A(I,:) q, ANY_SECONDI_INT64, frontier exchanged as lists", n_gpus=R.world,
+    rec = dict(case="BFS push steps w<!pi> = q(I)' A(I,:) per row block, ANY_SECONDI_INT64, found lists exchanged and merged", n_gpus=R.world,
                n=n, nnz=nnz, source=src, visited=int((level_of >= 0).sum()), total_ms=round(sec * 1e3, 2),
-               GTEPS=round(nnz / sec / 1e9, 3), levels=per_level, collective=bool(R.multi),
+               # slowest rank: time inside gba_vxm, inside the exchange; the rest of total_ms is the host's bookkeeping
+               # between levels (frontier and mask vectors built and uploaded, found lists merged)
+               product_ms=round(product_s * 1e3, 2), exchange_ms=round(exchange_s * 1e3, 2),
+               GTEPS=round(nnz / max(product_s + exchange_s, 1e-9) / 1e9, 3), levels=per_level, collective=bool(R.multi),
                workload=f"RMAT-{args.scale} ef=16 seed=42 symmetrised")
     return (level_of, parent), rec
 
