@@ -2483,6 +2483,8 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     if (A->vlen >= (int64_t)0x7fffffff) GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxpy3: vector length >= 2^31");
     if (M && (M->vlen != A->vlen || M->vdim != B->vdim)) GBA_FAIL(GBA_DIMENSION_MISMATCH, "saxpy3: mask dimensions");
     hipStream_t st = ctx().stream;
+    DevBuf sorted_i, sorted_x;
+    gba_matrix A_sorted;
     Saxpy3Plan P;
     P.A = SpView{A->p, A->i, A->x, A->iso};
     P.B = SpView{B->p, B->i, B->x, B->iso};
@@ -2642,6 +2644,34 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     // keep the memory-side accumulator kernels.
     // when the team takes every vector (the one vector of a frontier step) there is nothing to bin, count or size
     const bool all_team = nvec > 0 && (int64_t)P.team.size() == nvec;
+    // A jumbled A (the result of an earlier product, say) is multiplied as it is by the reference, whose Gustavson and
+    // hash tasks do not care about the order inside a vector.  The panel kernels do: when the product has several
+    // multiply-adds per entry of A, a sorted copy of A's indices and values is made first (the caller's matrix stays
+    // jumbled), which costs one segmented sort and keeps the heavy vectors off the memory-side accumulators.
+    if (A->jumbled && !all_team && !A->iso && nvec > 0 && A->nvals >= ((int64_t)1 << 16) && !getenv("GBA_SAXPY3_KEEP_JUMBLED")) {
+        DevBuf w; GBA_OK(w.alloc(16));
+        GBA_HIP(hipMemsetAsync(w.p, 0, 16, st));
+        int64_t blocks = ceil_div(nvec, 256); if (blocks > 512) blocks = 512;
+        hipLaunchKernelGGL(mask_work_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nvec, B->p, B->p, vflops.as<int64_t>(),
+                           w.as<unsigned long long>());
+        unsigned long long hw[2] = {0, 0};
+        GBA_HIP(hipMemcpyAsync(hw, w.p, 16, hipMemcpyDeviceToHost, st));
+        GBA_HIP(hipStreamSynchronize(st));
+        if ((double)hw[0] >= 4.0 * (double)A->nvals) {
+            int64_t aend = 0;
+            GBA_OK(dev_read_i64(A->p + A->nvec, &aend));
+            const size_t esize = esize_of(A->type);
+            GBA_OK(sorted_i.alloc((size_t)(aend > 0 ? aend : 1) * 8));
+            GBA_OK(sorted_x.alloc((size_t)(aend > 0 ? aend : 1) * esize));
+            GBA_HIP(hipMemcpyAsync(sorted_i.p, A->i, (size_t)aend * 8, hipMemcpyDeviceToDevice, st));
+            GBA_HIP(hipMemcpyAsync(sorted_x.p, A->x, (size_t)aend * esize, hipMemcpyDeviceToDevice, st));
+            A_sorted = *A;
+            A_sorted.i = sorted_i.as<int64_t>(); A_sorted.x = sorted_x.p;
+            GBA_OK(matrix_wait(&A_sorted));                // no zombies: sorts inside the two arrays above
+            A = &A_sorted;
+            P.A = SpView{A->p, A->i, A->x, A->iso};
+        }
+    }
     P.use_panels = !A->jumbled && !all_team;
     if (P.use_panels && B->nvals < A->nvals / 32 && nvec > 0) {
         // few entries in B: the product may still be large (a block of hub rows); the multiply-adds decide

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from graphblas_amd import Matrix, Type, Sparsity, gen
+from graphblas_amd import Matrix, DeviceMatrix, Type, Sparsity, gen
 from oracle import oracle
 from util import assert_same, assert_sums_within_bound
 
@@ -255,3 +255,30 @@ def test_one_pass_road_hands_over_when_a_vector_is_too_heavy(gba):
     want = oracle.saxpy3(None, False, False, A, B, "PLUS_TIMES_FP64")
     assert np.diff(want.p)[0] > 6144
     assert_same(got, want, exact=True)
+
+
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_a_jumbled_operand_of_a_large_product(gba, side):
+    """A*(A*A) and (A*A)*A: the first product comes back jumbled and is an operand of the second (held by row, the
+    right operand is the one whose vectors the kernels walk as sorted lists).  The library multiplies a
+    sorted copy (its panel kernels need sorted lists) and leaves the caller's matrix as it was; the result is that of
+    the sorted operand."""
+    A = gen.rmat(11, 8, seed=4, type=Type.FP64, values="int")
+    S = A.to_scipy()
+    dA = A.to_device()
+    dC = DeviceMatrix.empty(A.nrows, A.ncols, Type.FP64)
+    gba.mxm(dC, None, None, "PLUS_TIMES_FP64", dA, dA, None)
+    first = dC.to_host()
+    assert first.jumbled and first.nvals >= 1 << 16
+    dD = DeviceMatrix.empty(A.nrows, A.ncols, Type.FP64)
+    if side == "right":
+        gba.mxm(dD, None, None, "PLUS_TIMES_FP64", dA, dC, None)
+    else:
+        gba.mxm(dD, None, None, "PLUS_TIMES_FP64", dC, dA, None)
+    again = dC.to_host()
+    assert again.jumbled and np.array_equal(again.i, first.i) and np.array_equal(again.x, first.x)
+    want = (S @ S @ S).tocsr(); want.sort_indices()
+    got = dD.to_host().to_scipy(); got.sort_indices()
+    assert got.nnz == want.nnz and (got != want).nnz == 0           # small integers: exact
+    for d in (dA, dC, dD):
+        d.free()
