@@ -255,8 +255,11 @@ void     gba_matrix_free_content(gba_matrix *A);
  * Operands and C of another built-in real type than the semiring's are cast
  * (Source/GB_casting.h rules); hypersparse A, B, M and C are accepted; a C
  * that is hypersparse on entry is hypersparse on return, any other sparse
- * result stays sparse.  A product that replaces C and is iso-valued by the
- * rule of Source/GB_AxB_iso.c comes back with iso = true and one value in x.
+ * result stays sparse, unless C->hyper_switch asks for the reference's rule
+ * (see gba_matrix).  A C that is iso-valued on entry is accepted (its value
+ * is written out before the update).  A product that replaces C and is
+ * iso-valued by the rule of Source/GB_AxB_iso.c comes back with iso = true
+ * and one value in x.
  * A sparse mask far costlier than the product is left out of the multiply and
  * applied in the write-back (Source/GB_AxB_saxpy3_slice_balanced.c:309-403);
  * report->mask_applied tells which happened.

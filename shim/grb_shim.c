@@ -8,7 +8,7 @@
  *   3. everything is packed back (GxB_Matrix_pack_*, GxB_Vector_pack_*, 9342-9760).
  * A semiring over one user-defined type goes to gba_mxm_udt with the strings the application gave to
  * GxB_Type_new / GxB_BinaryOp_new (shim_run_udt).
- * A call the device path does not complete (casts to or from user-defined types, an iso-valued C, an operator
+ * A call the device path does not complete (casts to or from user-defined types, an operator
  * without a built-in code or definition, and EVERY gba_info other than GBA_SUCCESS: not implemented, out of
  * device memory, a compile error of a user-defined operator, a dimension or domain mismatch) goes to the next
  * definition of the same symbol, dlsym (RTLD_NEXT, ...): the CPU library, with its arguments untouched -- C is
@@ -471,7 +471,7 @@ static bool shim_run (int which, shim_call *k, const GrB_BinaryOp accum,
         return (false) ;                                /* a user-typed mask read by value: the CPU library's error */
     if (!shim_device_ready ()) return (false) ;
     gba_matrix cdev ;
-    if (k->c->v.iso || !shim_upload (&cdev, &(k->c->v), 0)) return (false) ;
+    if (!shim_upload (&cdev, &(k->c->v), 0)) return (false) ;      /* (an iso-valued C travels with its one value) */
     if (k->c->A != NULL)
     {
         /* the result is re-conformed to sparse or hypersparse by C's own hyper_switch, as GB_mxm ends (GB_conform) */

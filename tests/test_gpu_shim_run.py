@@ -298,3 +298,24 @@ def test_the_result_is_conformed_by_the_hyper_switch_of_C(libs, switch, want):
     else:
         assert got["sparsity"] == SPARSE
     fake.fake_matrix_free(A); fake.fake_matrix_free(Cm)
+
+
+def test_an_iso_valued_output_is_taken(libs):
+    """C += A*A where C holds one stored value for all its entries (as GrB_assign of a scalar leaves it): the call
+    stays on the device and the result is that of the same C with its values written out."""
+    shim, fake = libs
+    S = rmat_small(scale=7)
+    n = S.shape[0]
+    A = make_csr(fake, S, FP64)
+    P = sp.random(n, n, density=0.05, random_state=np.random.default_rng(2), format="csr")
+    P.sort_indices()
+    p, i = P.indptr.astype(np.int64), P.indices.astype(np.int64)
+    Cm = fake.fake_matrix_sparse(FP64, n, n, 1, 0, 0, ptr(p), None, ptr(i), ptr(np.array([2.0])), 1, 0)
+    before = fake.fake_cpu_calls(0)
+    assert shim.GrB_mxm(Cm, None, obj(fake, "GrB_PLUS_FP64"), obj(fake, "GrB_PLUS_TIMES_SEMIRING_FP64"), A, A, None) == 0
+    assert fake.fake_cpu_calls(0) == before, "the call fell through to the CPU library's stub"
+    got = look(fake, Cm, FP64)
+    Pw = sp.csr_matrix((np.full(P.nnz, 2.0), P.indices, P.indptr), shape=P.shape)
+    want = (Pw + S @ S).tocsr(); want.sort_indices()
+    assert not got["iso"] and got["S"].nnz == want.nnz and (got["S"] != want).nnz == 0
+    fake.fake_matrix_free(A); fake.fake_matrix_free(Cm)
