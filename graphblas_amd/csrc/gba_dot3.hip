@@ -251,10 +251,19 @@ constexpr int D3_THREADS = 1024;            // threads of a workgroup = mask ent
 #endif
 constexpr int D3_SLOTS = GBA_D3_SLOTS;       // slots of the LDS hash set
 constexpr int D3_SEG = D3_SLOTS / 2;        // keys of B(:,j) staged at a time
-constexpr int D3_HEAVY = 64;                // shortest B(:,j) worth staging
-constexpr int D3_SMALL = 16;                // longest A(:,i) one thread walks alone
+#ifndef GBA_D3_HEAVY
+#define GBA_D3_HEAVY 128
+#endif
+#ifndef GBA_D3_SMALL
+#define GBA_D3_SMALL 8
+#endif
+#ifndef GBA_D3_UNROLL
+#define GBA_D3_UNROLL 8
+#endif
+constexpr int D3_HEAVY = GBA_D3_HEAVY;       // shortest B(:,j) worth staging
+constexpr int D3_SMALL = GBA_D3_SMALL;       // longest A(:,i) one thread walks alone
 constexpr uint32_t D3_EMPTY = 0xffffffffu;
-constexpr int D3_UNROLL = 4;                // indices a lane loads per step of a streamed list
+constexpr int D3_UNROLL = GBA_D3_UNROLL;     // indices a lane loads per step of a streamed list
 
 // The hash set of the team kernel: buckets of four 32-bit keys, filled front to back, so one 16-byte LDS read
 // settles most lookups and a bucket whose last slot is empty ends the search.  Returns the slot of k, or -1.
