@@ -734,6 +734,128 @@ gba_info writeback_positions(gba_matrix *Cpos, const gba_matrix *M, bool has_acc
     GBA_FAIL(GBA_NOT_IMPLEMENTED, "C<M> = accum (C,T) with C of sparsity %d and T of sparsity %d", Cpos->sparsity, Tpos->sparsity);
 }
 
+// ------------------------------------------- accumulator of another type --
+// C<M> = accum (C,T) with an accumulator whose type U is not C's type Z (Test/GB_spec_accum.m:45-63, what GB_add
+// does inside Source/GB_accum_mask.c): where C and T both have an entry the result is (Z) accum ((U) c, (U) t), with
+// t cast from the monoid's type; an entry of T alone is (Z) t; an entry of C alone is kept bit for bit.  The
+// pattern work is the write-back on position codes (writeback_positions); three passes over the result then
+// compute the accumulated values in U, cast them to Z, and pick every entry's bytes from where its code says.
+__global__ void __launch_bounds__(256) place_codes_kernel(int64_t *x, int64_t n, int shift) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) x[p] = (p + 1) << shift;
+}
+
+template <class U>
+__global__ void __launch_bounds__(256)
+mixed_accum_kernel(int64_t n, const int64_t *__restrict__ code, const int8_t *__restrict__ Zb, const U *__restrict__ Cu,
+                   const U *__restrict__ Tu, bool T_iso, int op, U *__restrict__ Ru) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || (Zb && !Zb[e])) return;
+    const uint64_t w = (uint64_t)code[e];
+    const uint64_t lo = w & 0xffffffffull, hi = w >> 32;
+    if (lo && hi) Ru[e] = mult_tt<U>(op, Cu[lo - 1], Tu[T_iso ? 0 : hi - 1]);
+}
+
+__global__ void __launch_bounds__(256)
+mixed_select_kernel(int64_t n, const int64_t *__restrict__ code, const int8_t *__restrict__ Zb,
+                    const unsigned char *__restrict__ Cx, const unsigned char *__restrict__ Tz, bool T_iso,
+                    const unsigned char *__restrict__ Rz, unsigned char *__restrict__ out, int zs) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || (Zb && !Zb[e])) return;
+    const uint64_t w = (uint64_t)code[e];
+    const uint64_t lo = w & 0xffffffffull, hi = w >> 32;
+    const unsigned char *src = (lo && hi) ? Rz + e * zs : lo ? Cx + (lo - 1) * zs : Tz + (T_iso ? 0 : (hi - 1)) * zs;
+    for (int b = 0; b < zs; b++) out[e * zs + b] = src[b];
+}
+
+// T is in the monoid's type and in C's orientation; its pattern arrays are consumed, the caller frees the rest.
+static gba_info writeback_mixed_accum(const Call &k, const gba_matrix *M, gba_matrix *T) {
+    gba_matrix *C = k.C;
+    hipStream_t st = ctx().stream;
+    const int Zt = C->type, Ut = k.accum.type;
+    if (T->vlen != C->vlen || T->vdim != C->vdim) GBA_FAIL(GBA_PANIC, "write-back: T is %ld-by-%ld, C is %ld-by-%ld",
+                                                           (long)T->vlen, (long)T->vdim, (long)C->vlen, (long)C->vdim);
+    if (is_hyper(T) || is_hyper(C)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "write-back of a hypersparse matrix");
+    if (is_sparse(C) && is_dense_fmt(T)) GBA_OK(sparse_C_to_bitmap(C, k));
+    GBA_OK(spread_iso_values(C));
+    if (is_sparse(C) && (C->jumbled || C->nzombies)) GBA_OK(matrix_wait(C));
+    if (is_sparse(T) && (T->jumbled || T->nzombies)) GBA_OK(matrix_wait(T));
+    const int64_t nslots = C->vlen * C->vdim;
+    const int64_t cnz = is_dense_fmt(C) ? nslots : C->nvals, tnz = is_dense_fmt(T) ? nslots : T->nvals;
+    const int64_t most = ((int64_t)1 << 32) - 2;
+    if (cnz > most || tnz > most) GBA_FAIL(GBA_NOT_IMPLEMENTED, "accumulator of type %d into a C of type %d with more than 2^32 - 2 entries", Ut, Zt);
+    struct Guard { gba_matrix Cpos{}, Tpos{}; void *out = nullptr; std::vector<void *> owned;
+                   ~Guard() { gba_matrix_free_content(&Cpos); gba_matrix_free_content(&Tpos); gba_free(out); for (void *q : owned) gba_free(q); } } g;
+    // the values every case reads: T in U and in Z, C in U
+    gba_matrix Tu, Tz, Cu;
+    GBA_OK(cast_values(T, Ut, &Tu, g.owned));
+    GBA_OK(cast_values(T, Zt, &Tz, g.owned));
+    GBA_OK(cast_values(C, Ut, &Cu, g.owned));
+    const bool T_iso = T->iso;
+    auto dup = [&](const void *src, size_t bytes, void **dst) -> gba_info {
+        *dst = gba_malloc(bytes ? bytes : 1);
+        if (!*dst) GBA_FAIL(GBA_OUT_OF_MEMORY, "write-back copy of %zu bytes", bytes);
+        if (src && bytes) GBA_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyDeviceToDevice, st));
+        return GBA_SUCCESS;
+    };
+    auto codes = [&](int64_t n, int shift, void **dst) -> gba_info {
+        *dst = gba_malloc((size_t)(n > 0 ? n : 1) * 8);
+        if (!*dst) GBA_FAIL(GBA_OUT_OF_MEMORY, "position codes of %ld entries", (long)n);
+        if (n > 0) hipLaunchKernelGGL(place_codes_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, reinterpret_cast<int64_t *>(*dst), n, shift);
+        return GBA_SUCCESS;
+    };
+    gba_matrix &Cpos = g.Cpos, &Tpos = g.Tpos;
+    Cpos = *C; Cpos.type = GBA_INT64; Cpos.p = Cpos.i = Cpos.h = nullptr; Cpos.x = nullptr; Cpos.b = nullptr; Cpos.iso = false;
+    if (is_sparse(C)) {
+        GBA_OK(dup(C->p, (size_t)(C->nvec + 1) * 8, (void **)&Cpos.p));
+        GBA_OK(dup(C->i, (size_t)cnz * 8, (void **)&Cpos.i));
+    } else if (is_bitmap(C)) {
+        GBA_OK(dup(C->b, (size_t)nslots, (void **)&Cpos.b));
+    }
+    GBA_OK(codes(cnz, 0, &Cpos.x));
+    Tpos = *T; Tpos.type = GBA_INT64; Tpos.iso = false; Tpos.x = nullptr;
+    T->p = T->i = T->h = nullptr; T->b = nullptr;            // the pattern of T now belongs to Tpos; T keeps its values
+    GBA_OK(codes(tnz, 32, &Tpos.x));
+    GBA_HIP(hipGetLastError());
+    GBA_OK(writeback_positions(&Cpos, M, true, k.C_replace, k.Mask_comp, k.Mask_struct, &Tpos));
+    const int64_t zn = is_dense_fmt(&Cpos) ? nslots : Cpos.nvals;
+    const size_t zs = type_size(Zt), us = type_size(Ut);
+    g.out = gba_malloc((size_t)(zn > 0 ? zn : 1) * zs);
+    if (!g.out) GBA_FAIL(GBA_OUT_OF_MEMORY, "values of the result");
+    if (zn > 0) {
+        const int8_t *Zb = is_bitmap(&Cpos) ? Cpos.b : nullptr;
+        const int64_t *code = reinterpret_cast<const int64_t *>(Cpos.x);
+        void *Ru = gba_malloc((size_t)zn * us);
+        if (!Ru) GBA_FAIL(GBA_OUT_OF_MEMORY, "accumulated values");
+        g.owned.push_back(Ru);
+        GBA_HIP(hipMemsetAsync(Ru, 0, (size_t)zn * us, st));
+        const unsigned blocks = (unsigned)ceil_div(zn, 256);
+        GBA_OK(with_type(Ut, [&](auto u) -> gba_info {
+            using U = decltype(u);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(mixed_accum_kernel<U>), dim3(blocks), dim3(256), 0, st, zn, code, Zb,
+                               reinterpret_cast<const U *>(Cu.x), reinterpret_cast<const U *>(Tu.x), T_iso, (int)k.accum.op,
+                               reinterpret_cast<U *>(Ru));
+            return GBA_SUCCESS;
+        }));
+        GBA_HIP(hipGetLastError());
+        gba_matrix R{}, Rz;
+        R.vlen = zn; R.vdim = R.nvec = 1; R.nvals = zn; R.sparsity = GBA_FULL; R.type = Ut; R.x = Ru; R.mem = GBA_MEM_DEVICE; R.is_csc = true;
+        GBA_OK(cast_values(&R, Zt, &Rz, g.owned));
+        hipLaunchKernelGGL(mixed_select_kernel, dim3(blocks), dim3(256), 0, st, zn, code, Zb,
+                           reinterpret_cast<const unsigned char *>(C->x), reinterpret_cast<const unsigned char *>(Tz.x), T_iso,
+                           reinterpret_cast<const unsigned char *>(Rz.x), reinterpret_cast<unsigned char *>(g.out), (int)zs);
+        GBA_HIP(hipGetLastError());
+    }
+    GBA_HIP(hipStreamSynchronize(st));
+    const float hs = C->hyper_switch;
+    free_unaliased(C, k);                                    // the old arrays were read above
+    gba_free(Cpos.x);
+    *C = Cpos;
+    C->x = g.out; C->type = Zt; C->iso = false; C->hyper_switch = hs;
+    g.out = nullptr; Cpos = gba_matrix{};                   // handed over
+    return GBA_SUCCESS;
+}
+
 // Format combinations no specialised kernel takes (dense A with sparse B, two dense operands under a
 // sparse result, two sparse operands in dot form, ...).  The CPU has a template instance for every
 // combination (Source/Template/GB_AxB_dot2_meta.c, GB_AxB_saxbit_template.c); here the operands are
@@ -943,6 +1065,10 @@ static gba_info mxm_driver_sparse_C(Call k, gba_report *report, bool select_only
     if (cast_T && (!is_real_type(C->type) || !is_real_type(k.semiring.ztype)))
         GBA_FAIL(GBA_NOT_IMPLEMENTED, "C has type %d, the monoid %d (complex and user-defined types are not cast on the device)", C->type, k.semiring.ztype);
     if (k.has_accum && op_is_positional(k.accum.op)) GBA_FAIL(GBA_DOMAIN_MISMATCH, "positional accum");
+    // an accumulator of another type than C works in its own type (Test/GB_spec_accum.m:45-63): built-in real types
+    const bool mixed_accum = k.has_accum && k.accum.type != C->type;
+    if (mixed_accum && (!is_real_type(k.accum.type) || !is_real_type(C->type) || !is_real_type(k.semiring.ztype) || !accum_op_ok(k.accum.op)))
+        GBA_FAIL(GBA_NOT_IMPLEMENTED, "accum operator %d of type %d into a C of type %d over a monoid of type %d", k.accum.op, k.accum.type, C->type, k.semiring.ztype);
 
     // mask shortcuts (Source/GB_mxm.c:105-114)
     const gba_matrix *M = k.M;
@@ -1125,8 +1251,8 @@ static gba_info mxm_driver_sparse_C(Call k, gba_report *report, bool select_only
         T = TT;
         T.is_csc = C_is_csc;
     }
-    if (cast_T) {
-        // Z = accum (C, cast (T)): the accumulator works in C's type (Source/GB_accum_mask.c)
+    if (cast_T && !mixed_accum) {
+        // Z = accum (C, cast (T)): the accumulator has C's type (Source/GB_accum_mask.c)
         gba_matrix Tc;
         std::vector<void *> mine;
         info = cast_values(&T, C->type, &Tc, mine);
@@ -1161,6 +1287,11 @@ static gba_info mxm_driver_sparse_C(Call k, gba_report *report, bool select_only
         if (info != GBA_SUCCESS) { gba_matrix_free_content(&T); return info; }
         Mturned.is_csc = C_is_csc;
         Mwb = &Mturned;
+    }
+    if (mixed_accum) {
+        info = writeback_mixed_accum(k, Mwb, &T);
+        gba_matrix_free_content(&T);
+        return info;
     }
     if (is_dense_fmt(C)) {
         info = writeback_dense(k, Mwb, &T);

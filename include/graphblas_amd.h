@@ -260,6 +260,11 @@ void     gba_matrix_free_content(gba_matrix *A);
  * is written out before the update).  A product that replaces C and is
  * iso-valued by the rule of Source/GB_AxB_iso.c comes back with iso = true
  * and one value in x.
+ * An accumulator of another built-in real type than C works in its own type
+ * (Test/GB_spec_accum.m:45-63, GB_add inside Source/GB_accum_mask.c): where C
+ * and the product both have an entry, both are cast to it and the result to
+ * C's type; an entry of the product alone is cast to C's type, an entry of C
+ * alone is kept bit for bit (up to 2^32 - 2 entries each in C and the product).
  * A sparse mask far costlier than the product is left out of the multiply and
  * applied in the write-back (Source/GB_AxB_saxpy3_slice_balanced.c:309-403);
  * report->mask_applied tells which happened.
@@ -272,7 +277,7 @@ void     gba_matrix_free_content(gba_matrix *A);
  * gba_mxm_udt (operators compiled by hipRTC, one dot product per entry) and
  * share its limits.
  * Returns GBA_NOT_IMPLEMENTED for valid calls outside the device path
- * (user-defined ops -- see gba_mxm_udt --, an accumulator of another type than C, ...):
+ * (user-defined ops -- see gba_mxm_udt --, a complex accumulator on a real C, ...):
  * the caller keeps the CPU library for those, like the GB_cuda_*_branch test
  * in Source/GB_AxB_dot.c:189-197. */
 gba_info gba_mxm(gba_matrix *C, const gba_matrix *M, const gba_binop *accum,

@@ -789,15 +789,17 @@ int orc_mxm_spec(int8_t *present, void *value, int64_t nrows, int64_t ncols, int
                  bool C_replace, bool Mask_comp, bool Mask_struct) {
     orc_semiring s;
     if (orc_semiring_builtin(&s, sr_in, false) != 0) return -1;
-    /* value[] and the accumulator have the type of C; T is cast to it before the accumulator sees it, and
-       the operands are cast to the multiplier's input types (Source/GB_mxm.c:84-99; GB_accum_mask) */
+    /* value[] has the type of C.  The accumulator works in its own type: where C and T both have an entry, C's is
+       cast to it, T's is cast to it from the monoid's type, and the result is cast to C's type; an entry of T
+       alone is cast to C's type, an entry of C alone stays as it is (Test/GB_spec_accum.m:45-63).  The operands
+       are cast to the multiplier's input types (Source/GB_mxm.c:84-99) */
     const size_t zs = orc_type_size(C->type);
     const bool cast_t = (C->type != s.ztype);
     const bool cast_a = !s.positional && A->type != s.xtype, cast_b = !s.positional && B->type != s.xtype;
     if (cast_t && s.ztype == GBA_UDT) return -1;
     binfn facc = NULL;
     if (accum && accum->op != GBA_NOP) {
-        if (accum->type != C->type) return -1;
+        if (accum->type != C->type && (accum->type >= GBA_FC32 || C->type >= GBA_FC32 || s.ztype >= GBA_FC32)) return -1;
         facc = lookup_binop(accum->type == GBA_BOOL ? bool_rename(accum->op) : accum->op, accum->type); if (!facc) return -1;
     }
     #pragma omp parallel for schedule(dynamic, 4)
@@ -827,6 +829,8 @@ int orc_mxm_spec(int8_t *present, void *value, int64_t nrows, int64_t ncols, int
                 else s.fmult(tk, a, b);
                 if (t_in) s.fadd(t, t, tk); else { memcpy(t, tk, s.zsize); t_in = true; }
             }
+            uint8_t traw[ORC_MAX_VALUE];                                     /* T(r,c) in the monoid's type */
+            if (t_in) memcpy(traw, t, s.zsize);
             if (t_in && cast_t) { uint8_t tc[ORC_MAX_VALUE]; orc_cast(tc, C->type, t, s.ztype); memcpy(t, tc, zs); }
             /* Z = accum (C,T); C<M,replace> = Z */
             const void *cv; const bool c_in = get_entry(C, r, c, &cv, zs);
@@ -839,7 +843,17 @@ int orc_mxm_spec(int8_t *present, void *value, int64_t nrows, int64_t ncols, int
             if (Mask_comp) m = !m;
             uint8_t z[ORC_MAX_VALUE]; bool z_in;
             if (facc) {
-                if (c_in && t_in) { facc(z, cv, t); z_in = true; }
+                if (c_in && t_in) {
+                    if (accum->type == C->type) facc(z, cv, t);
+                    else {
+                        uint8_t cu[ORC_MAX_VALUE], tu[ORC_MAX_VALUE], zu[ORC_MAX_VALUE];
+                        orc_cast(cu, accum->type, cv, C->type);
+                        orc_cast(tu, accum->type, traw, s.ztype);
+                        facc(zu, cu, tu);
+                        orc_cast(z, C->type, zu, accum->type);
+                    }
+                    z_in = true;
+                }
                 else if (c_in) { memcpy(z, cv, zs); z_in = true; }
                 else if (t_in) { memcpy(z, t, zs); z_in = true; }
                 else z_in = false;

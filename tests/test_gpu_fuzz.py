@@ -159,6 +159,36 @@ def test_random_call_with_typecasts(gba, seed):
     _check(gba, seed, *_cast_case(seed))
 
 
+def _mixed_accum_case(seed):
+    """As _cast_case, with an accumulator of a type that is not C's."""
+    rng = np.random.default_rng(9000 + seed)
+    sr, t, _ = SEMIRINGS[rng.integers(len(SEMIRINGS))]
+    m, k, n = (int(x) for x in rng.integers(1, 30, 3))
+    ta, tb, tc = (CAST_TYPES[rng.integers(len(CAST_TYPES))] for _ in range(3))
+    tu = [u for u in CAST_TYPES if u != tc][rng.integers(len(CAST_TYPES) - 1)]
+    fm = lambda: ["sparse", "sparse", "bitmap", "full"][rng.integers(4)]
+    A = _typed_matrix(rng, m, k, ta, fm(), bool(rng.random() < 0.5), 0.4)
+    B = _typed_matrix(rng, k, n, tb, fm(), bool(rng.random() < 0.5), 0.4)
+    c_by_row = bool(rng.random() < 0.5)
+    C0 = Matrix.sparse_empty(m, n, tc, by_row=c_by_row) if rng.random() < 0.15 else _typed_matrix(rng, m, n, tc, fm(), c_by_row, 0.4)
+    M = None
+    if rng.random() < 0.5:
+        M = _random_matrix(rng, m, n, Type.INT8, ["sparse", "bitmap", "full"][rng.integers(3)], bool(rng.random() < 0.5), 0.4)
+        M.x = (M.x % 2).astype(np.int8)
+    uname = {v: k_ for k_, v in vars(Type).items() if isinstance(v, int)}[tu]
+    ops = ["LOR", "LXOR", "LAND"] if tu == Type.BOOL else ["PLUS", "MIN", "MAX", "SECOND", "FIRST", "TIMES", "MINUS"]
+    accum = f"{ops[rng.integers(len(ops))]}_{uname}"
+    desc = ("R" if rng.random() < 0.3 else "") + (("S" if rng.random() < 0.5 else "") + ("C" if rng.random() < 0.4 else "") if M is not None else "")
+    return sr, A, B, C0, M, accum, desc, False
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_call_with_an_accumulator_of_another_type(gba, seed):
+    """Z = accum (C,T) in the accumulator's own type (Test/GB_spec_accum.m:45-63): both operands cast to it, the
+    result cast to C's type, entries of C alone kept bit for bit, entries of T alone cast to C's type."""
+    _check(gba, seed, *_mixed_accum_case(seed))
+
+
 @pytest.mark.parametrize("seed", range(500, 548))
 def test_random_call_matches_the_definition_larger(gba, seed):
     """Dimensions of 120..320: vectors reach the block-level hash kernels and the long-row dot paths."""

@@ -419,7 +419,7 @@ def test_costly_sparse_mask_is_discarded_and_applied_afterwards(gba, desc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("failure", ["dimension", "accum_type"])
+@pytest.mark.parametrize("failure", ["dimension", "accum_op"])
 def test_a_hypersparse_C_is_untouched_by_a_call_that_fails(gba, failure):
     """A call that fails validation (or is declined) must hand a hypersparse C back as it came -- hypersparse, the
     same list of vectors, the same entries -- so that a caller which falls back to the CPU library finds its C
@@ -433,7 +433,7 @@ def test_a_hypersparse_C_is_untouched_by_a_call_that_fails(gba, failure):
     A = Matrix.from_scipy(sp.random(n + (1 if failure == "dimension" else 0), n, density=0.02, format="csr", random_state=8), type=Type.FP64)
     B = Matrix.from_scipy(sp.random(n, n, density=0.02, format="csr", random_state=9), type=Type.FP64)
     dC, dA, dB = C0.to_device(), A.to_device(), B.to_device()
-    accum = "PLUS_INT32" if failure == "accum_type" else None
+    accum = "POW_FP64" if failure == "accum_op" else None       # an accumulator the write-back has no code for
     with pytest.raises(GrbError) as err:
         g.mxm(dC, None, accum, "PLUS_TIMES_FP64", dA, dB, None)
     assert err.value.info == (Info.DIMENSION_MISMATCH if failure == "dimension" else Info.NOT_IMPLEMENTED)

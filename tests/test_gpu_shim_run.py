@@ -203,6 +203,29 @@ def test_relaxation_with_the_distance_vector_as_input_and_output(libs):
     fake.fake_matrix_free(Ah); fake.fake_vector_free(d)
 
 
+def test_an_accumulator_of_another_type_than_C_is_taken(libs):
+    """GrB_mxm (C, NULL, GrB_PLUS_INT64, GrB_PLUS_TIMES_SEMIRING_FP64, A, A, NULL) with an FP64 C: where C and the
+    product both have an entry the sum is made in int64 (both truncated), the other entries keep their fractions."""
+    shim, fake = libs
+    S = rmat_small(values="int").astype(np.float64)
+    S.data += 0.5                                                    # halves: products and sums stay exact in fp64
+    A = make_csr(fake, S, FP64)
+    C0 = sp.random(S.shape[0], S.shape[1], density=0.05, format="csr", random_state=4, dtype=np.float64)
+    C0.data = np.round(C0.data * 64) / 8 + 0.125
+    Cm = make_csr(fake, C0, FP64)
+    before = fake.fake_cpu_calls(0)
+    info = shim.GrB_mxm(Cm, None, obj(fake, "GrB_PLUS_INT64"), obj(fake, "GrB_PLUS_TIMES_SEMIRING_FP64"), A, A, None)
+    assert info == 0 and fake.fake_cpu_calls(0) == before, "the call went to the CPU library"
+    got = look(fake, Cm, FP64)["S"]
+    T = (S @ S).tocsr()
+    both = C0.multiply(T != 0).astype(bool)                          # pattern of the intersection
+    c, t = C0.toarray(), T.toarray()
+    want = np.where(both.toarray(), np.trunc(c) + np.trunc(t), np.where(c != 0, c, t))
+    pattern = (c != 0) | ((S != 0).astype(np.int64) @ (S != 0).astype(np.int64)).toarray().astype(bool)
+    assert np.array_equal(got.toarray(), want) and got.nnz == int(pattern.sum())
+    fake.fake_matrix_free(A); fake.fake_matrix_free(Cm)
+
+
 def test_a_declined_call_reaches_the_cpu_library_with_its_handles_intact(libs):
     """A semiring the device path has no code for (PLUS_POW): the stub behind dlsym (RTLD_NEXT) is reached, and C, A
     hold exactly what they held."""

@@ -214,6 +214,28 @@ def test_mxm_spec_typecasts_operands_and_result():
     assert p.all() and v.dtype == np.float32 and np.array_equal(v, want.astype(np.float32))
 
 
+def test_accumulator_of_another_type_works_in_its_own_type():
+    """Test/GB_spec_accum.m:45-63: where C and T both have an entry, both are cast to the accumulator's type and the
+    result is cast to C's; an entry of C alone is kept as it is, an entry of T alone is cast to C's type."""
+    A = Matrix.dense(np.array([[300.5, 0.0], [2.5, 1.0]], np.float64))
+    B = Matrix.dense(np.array([[1.0, 0.0], [0.0, 1.0]], np.float64), present=np.array([[True, False], [False, True]]))
+    C0 = Matrix.dense(np.array([[10.7, 20.9], [0.0, -3.25]], np.float64), present=np.array([[True, True], [False, True]]))
+    p, v = oracle.mxm_spec(C0, None, "PLUS_INT8", "PLUS_TIMES_FP64", A, B)
+    # T = A*B = [[300.5, 0], [2.5, 1]], every entry present (A is full; B's pattern picks one term each)
+    # (0,0): int8 (10.7) + int8 (300.5) = 10 + 127 = 137 -> wraps to -119;  (0,1): 20 + 0 = 20;  (1,0): T alone -> 2.5;
+    # (1,1): -3 + 1 = -2
+    assert p.all() and v.dtype == np.float64
+    assert v.tolist() == [[-119.0, 20.0], [2.5, -2.0]]
+    # under a mask that hides (0,1), that entry of C stays 20.9
+    M = Matrix.dense(np.array([[1, 0], [1, 1]], np.int8))
+    p, v = oracle.mxm_spec(C0, M, "PLUS_INT8", "PLUS_TIMES_FP64", A, B)
+    assert v.tolist() == [[-119.0, 20.9], [2.5, -2.0]]
+    # T is cast to the accumulator's type from the monoid's type, not through C's: int8 C, fp64 accumulator
+    C1 = Matrix.dense(np.array([[1, 1], [1, 1]], np.int8))
+    p, v = oracle.mxm_spec(C1, None, "PLUS_FP64", "PLUS_TIMES_FP64", A, B)
+    assert v.dtype == np.int8 and v.tolist() == [[127, 1], [3, 2]]     # 1 + 300.5 = 301.5 saturates; 1 + 2.5 = 3.5 -> 3
+
+
 def _rand_complex(n, m, density, seed, t=Type.FC64, by_row=True, gaussian_integers=True):
     rng = np.random.default_rng(seed)
     S = sp.random(n, m, density=density, random_state=rng, format="csr").astype(np.complex128)
