@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the row-sum check of every chunk in the first warm-up step")
     ap.add_argument("--no-spmv", action="store_true", help="leave out the SpMV leg reported beside the headline")
     ap.add_argument("--cpu-flops", type=float, default=8e9, help="multiply-adds in the CPU baseline sample")
+    ap.add_argument("--b-panels", type=int, default=0,
+                    help="N > 1: exchange the right-hand operand one column panel at a time (this many panels) "
+                         "instead of gathering it whole -- for a B that does not fit on every rank")
     return ap.parse_args()
 
 
@@ -100,7 +103,7 @@ def main():
         os.close(saved_stdout)
     import graphblas_amd as g
     from graphblas_amd import gen, Type, DeviceMatrix, Matrix
-    from graphblas_amd.dist import row_flops, split_by_flops, chunks_by_flops, RowBlockExchange
+    from graphblas_amd.dist import row_flops, split_by_flops, chunks_by_flops, RowBlockExchange, ColumnPanelExchange
     from graphblas_amd.binding import gba_matrix
     g.init(local_rank)
 
@@ -114,13 +117,14 @@ def main():
 
     # device copies.  Right-hand operand: full A on every rank, held in torch tensors so that RCCL can fill them.
     dev = torch.device("cuda", local_rank)
+    panels = args.b_panels if multi else 0               # > 0: B travels one column panel at a time and is never whole
     Bp = torch.from_numpy(A.p).to(dev)
-    Bi = torch.empty(nnzA, dtype=torch.int64, device=dev)
-    Bx = torch.empty(nnzA, dtype=torch.float64, device=dev)
+    Bi = torch.empty(1 if panels else nnzA, dtype=torch.int64, device=dev)
+    Bx = torch.empty(1 if panels else nnzA, dtype=torch.float64, device=dev)
 
     # 1-D partition of rows over ranks, balanced by flops: the library's own split (the per-vector count saxpy3
     # bins by, gba_partition_by_flops), taken once on the pattern before the timed region
-    if multi:
+    if multi and not panels:
         Bi.copy_(torch.from_numpy(A.i))
         m0 = gba_matrix()
         m0.vlen, m0.vdim, m0.nvec, m0.nvals = n, n, n, nnzA
@@ -151,6 +155,36 @@ def main():
         return DeviceMatrix(m, owns=False)
 
     Bfull = view_rows(0, n)
+    if panels:
+        # the rank keeps its own row block twice: whole, as the left operand A(I,:), and cut into column panels, as its
+        # share of the right operand; one gathered panel B(:, J_c) is resident at a time
+        xc = ColumnPanelExchange(dist, torch, part, rank, n, A.p[my_lo:my_hi + 1], A.i[e_lo:e_hi], panels, dev, collective=True)
+        my_i_perm = torch.from_numpy(A.i[e_lo:e_hi][xc.perm]).to(dev)
+        my_x_perm = torch.from_numpy(A.x[e_lo:e_hi][xc.perm]).to(dev)
+        room = max(max(xc.panel_nnz), 1)
+        Pi = torch.empty(room, dtype=torch.int64, device=dev)
+        Px = torch.empty(room, dtype=torch.float64, device=dev)
+        panel_p = [torch.from_numpy(pp).to(dev) for pp in xc.panel_p]
+        my_p = torch.from_numpy((A.p[my_lo:my_hi + 1] - e_lo).astype(np.int64)).to(dev)
+        panel_chunks = []
+        for c in range(panels):
+            pc = np.concatenate([[0], np.cumsum(row_flops(A.p, A.i, xc.panel_p[c]))]).astype(np.int64)
+            panel_chunks.append(chunks_by_flops(pc, my_lo, my_hi, args.chunk_flops))
+
+        def own_rows(lo, hi):
+            m = gba_matrix()
+            m.vlen, m.vdim, m.nvec = n, hi - lo, hi - lo
+            m.nvals = int(A.p[hi] - A.p[lo])
+            m.p, m.i, m.x = my_p.data_ptr() + 8 * (lo - my_lo), my_i.data_ptr(), my_x.data_ptr()
+            m.type, m.sparsity, m.mem, m.is_csc = Type.FP64, g.Sparsity.SPARSE, 0, False
+            return DeviceMatrix(m, owns=False)
+
+        def panel_view(c):
+            m = gba_matrix()
+            m.vlen, m.vdim, m.nvec, m.nvals = n, n, n, xc.panel_nnz[c]
+            m.p, m.i, m.x = panel_p[c].data_ptr(), Pi.data_ptr(), Px.data_ptr()
+            m.type, m.sparsity, m.mem, m.is_csc = Type.FP64, g.Sparsity.SPARSE, 0, False
+            return DeviceMatrix(m, owns=False)
     sr = g.semiring("PLUS_TIMES_FP64")
     stats = {"phase_ms": np.zeros(8), "cnz": 0, "bins": np.zeros(4, np.int64), "bin_cnz": np.zeros(4, np.int64),
              "bin_bnz": np.zeros(4, np.int64), "bin_madds": np.zeros(4, np.int64), "launches": 0}
@@ -163,15 +197,20 @@ def main():
     vecs = [np.ones(n), np.random.default_rng(7).random(n) + 0.5]
     checks = None
 
-    def verify_chunk(Cc, lo, hi, cnz):
+    def verify_chunk(Cc, lo, hi, cnz, cols=None):
+        """cols = (j0, j1): the chunk holds the columns j0:j1 of its rows only (a column panel of B)."""
         nonlocal checks
         if checks is None:
             S = A.to_scipy()
-            checks = [(Matrix.full_vector(v).to_device(), S, S @ v) for v in vecs]
+            checks = [(Matrix.full_vector(v).to_device(), S, {None: S @ v}, v) for v in vecs]
         u = np.finfo(np.float64).eps / 2
-        if Cc.view.nvals != cnz or cnz <= 0:
+        if Cc.view.nvals != cnz or (cnz <= 0 and cols is None):
             verify["nnz_ok"] = False
-        for dv, S, Av in checks:
+        for dv, S, Avs, v in checks:
+            if cols not in Avs:
+                Avs.clear()                                  # one panel's product at a time
+                Avs[cols] = S[:, cols[0]:cols[1]] @ v[cols[0]:cols[1]]
+            Av = Avs[cols]
             y = Matrix.full_vector(np.zeros(hi - lo)).to_device()
             g.mxv(y, None, "PLUS_FP64", sr, Cc, dv)                      # y = C_I v on the device (dot4)
             got = y.to_host().x
@@ -188,32 +227,45 @@ def main():
         verify["rows"] += hi - lo
 
     def step(collect, check=False):
-        exchange()
-        torch.cuda.synchronize()
-        for lo, hi in my_chunks:
-            Cc = DeviceMatrix.empty(hi - lo, n, Type.FP64)
-            tw = time.perf_counter()
-            rep = g.mxm(Cc, None, None, sr, view_rows(lo, hi), Bfull, None)
-            if check:
-                verify_chunk(Cc, lo, hi, rep.cnz)
-            if os.environ.get("GBA_BENCH_DEBUG"):
-                tw1 = time.perf_counter()
-                Cc.free(); g.sync()
-                print(f"[bench] rows {lo}:{hi} mxm wall {1e3 * (tw1 - tw):.1f} ms kernel_ms {rep.kernel_ms:.1f} "
-                      f"free {1e3 * (time.perf_counter() - tw1):.1f} ms cnz {rep.cnz} phases "
-                      f"{[round(x, 1) for x in rep.phase_ms[:7]]} bins {list(rep.bin_vectors)}", file=sys.stderr)
-            if collect:
-                stats["phase_ms"] += np.array(rep.phase_ms[:])
-                stats["cnz"] += rep.cnz
-                stats["bins"] += np.array(rep.bin_vectors[:])
-                stats["bin_cnz"] += np.array(rep.bin_cnz[:])
-                stats["bin_bnz"] += np.array(rep.bin_bnz[:])
-                stats["bin_madds"] += np.array(rep.bin_madds[:])
-                stats["launches"] += 1
-                stats["panels"] = stats.get("panels", 0) + rep.panels
-                stats["panels_redone"] = stats.get("panels_redone", 0) + rep.panels_redone
-            Cc.free()
+        if not panels:
+            exchange()
+            torch.cuda.synchronize()
+            for lo, hi in my_chunks:
+                one_product(collect, check, None, lo, hi)
+        else:
+            for c in range(panels):                          # every rank walks the panels in the same order
+                xc.gather(c, my_i_perm, my_x_perm, Pi, Px)
+                torch.cuda.synchronize()
+                for lo, hi in panel_chunks[c]:
+                    one_product(collect, check, c, lo, hi)
         g.sync()
+
+    def one_product(collect, check, c, lo, hi):
+        Cc = DeviceMatrix.empty(hi - lo, n, Type.FP64)
+        tw = time.perf_counter()
+        if c is None:
+            rep = g.mxm(Cc, None, None, sr, view_rows(lo, hi), Bfull, None)
+        else:
+            rep = g.mxm(Cc, None, None, sr, own_rows(lo, hi), panel_view(c), None)
+        if check:
+            verify_chunk(Cc, lo, hi, rep.cnz, None if c is None else (xc.cuts[c], xc.cuts[c + 1]))
+        if os.environ.get("GBA_BENCH_DEBUG"):
+            tw1 = time.perf_counter()
+            Cc.free(); g.sync()
+            print(f"[bench] rows {lo}:{hi} mxm wall {1e3 * (tw1 - tw):.1f} ms kernel_ms {rep.kernel_ms:.1f} "
+                  f"free {1e3 * (time.perf_counter() - tw1):.1f} ms cnz {rep.cnz} phases "
+                  f"{[round(x, 1) for x in rep.phase_ms[:7]]} bins {list(rep.bin_vectors)}", file=sys.stderr)
+        if collect:
+            stats["phase_ms"] += np.array(rep.phase_ms[:])
+            stats["cnz"] += rep.cnz
+            stats["bins"] += np.array(rep.bin_vectors[:])
+            stats["bin_cnz"] += np.array(rep.bin_cnz[:])
+            stats["bin_bnz"] += np.array(rep.bin_bnz[:])
+            stats["bin_madds"] += np.array(rep.bin_madds[:])
+            stats["launches"] += 1
+            stats["panels"] = stats.get("panels", 0) + rep.panels
+            stats["panels_redone"] = stats.get("panels_redone", 0) + rep.panels_redone
+        Cc.free()
 
     def fence():
         torch.cuda.synchronize()
@@ -225,7 +277,7 @@ def main():
         step(False, check=(w == 0 and not args.no_verify))
     checked = args.warmup > 0 and not args.no_verify
     if checks is not None:
-        for dv, _, _ in checks:
+        for dv, *_ in checks:
             dv.free()
         checks = None
     fence()
@@ -273,9 +325,9 @@ def main():
             "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"RMAT-{args.scale} ef={args.edge_factor} seed=42 C=A*A via gba_mxm (CSR, int64 indices), "
-                                   f"{len(my_chunks)} row chunks on rank 0, C released per chunk",
+                                   f"{sum(len(pc) for pc in panel_chunks) if panels else len(my_chunks)} row chunks on rank 0, C released per chunk",
                        "n": n, "nnz_A": nnzA, "multiply_adds": total_madds, "nnz_C": cnz_all,
-                       "parallelism": f"rowblock{world}" + ("+allgatherB" if multi else "")},
+                       "parallelism": f"rowblock{world}" + ((f"+{panels}columnpanelsB" if panels else "+allgatherB") if multi else "")},
             "hbm_GBps_compulsory": round(compulsory / sec_per_step / 1e9, 2),
             "phase_ms_per_step_rank0": [round(float(x) / args.steps, 3) for x in stats["phase_ms"]],
             "numeric_bin_vectors_rank0": [int(x) // max(args.steps, 1) for x in stats["bins"]],
@@ -297,7 +349,7 @@ def main():
             "verification": {"chunks": verify["chunks"], "rows": verify["rows"], "vectors": len(vecs),
                              "worst_error_over_bound": round(verify["worst_ratio"], 4)},
         }
-        if world == 1 and not args.no_spmv:                   # second workload of the path, outside the timed region
+        if world == 1 and not args.no_spmv and not panels:                   # second workload of the path, outside the timed region
             out["spmv"] = spmv_leg(g, torch, A, Bp, Bi, Bx, dev, args)
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on the one-GPU run only
             out["cpu_baseline"] = cpu_baseline(A, rf, args.cpu_flops)

@@ -10,6 +10,9 @@ The other products of the path shard the same way, by row blocks of the output: 
 all-gather of x (VectorBlockExchange), a traversal step w(I)<!visited> = A(I,:) q the exchange of the
 frontier (FrontierExchange: index lists while it is small, a dense reduce once it is large).
 
+When B does not fit whole on every rank it is exchanged one column panel at a time instead
+(ColumnPanelExchange): C(I, J) = A(I,:)*B(:, J), the panels of C are disjoint, nothing is reduced.
+
 The helpers work on any torch.distributed backend ("nccl" is RCCL on ROCm; "gloo" on CPU).
 """
 import numpy as np
@@ -115,6 +118,84 @@ class RowBlockExchange:
             return
         for mine, out in ((my_i, out_i), (my_x, out_x)):
             all_gather_in_place(self.dist, self.torch, mine, out, self.offs, self.counts, self.rank)
+
+
+class ColumnPanelExchange:
+    """The right-hand operand when it does not fit whole on every rank: B, distributed by row blocks, is exchanged
+    one column panel at a time.  The columns are cut into contiguous ranges J_0 .. J_{q-1} that hold about equal
+    numbers of entries; every rank keeps its row block cut the same way (pieces B(K_r, J_c): CSR, global column
+    indices), panel c of the whole matrix is the all-gather of the pieces c, each received at its own length
+    straight into its place, and C(I, J_c) = A(I,:) * B(:, J_c).  The panels of C are disjoint column ranges, so
+    nothing is accumulated or reduced, and a rank holds one panel (1/q of B) beside its own block.
+
+    Set-up needs the rank's own block only (host arrays): one SUM all-reduce of the column counts fixes the cuts,
+    one all-gather per panel of the per-row counts gives every rank the row pointers of the gathered panel.
+      perm          permutation of the block's entries that lays the pieces one after the other (rows ascending
+                    inside a piece); the caller keeps my_i[perm], my_x[perm]
+      piece[c]      (start, end) of piece c in the permuted arrays
+      panel_p[c]    row pointers (n + 1, int64) of the gathered panel c;  panel_nnz[c] its entries"""
+
+    def __init__(self, dist, torch, part, rank, ncols, my_p, my_i, npanels, device, collective=None):
+        self.dist, self.torch, self.rank = dist, torch, rank
+        self.world = len(part) - 1
+        self.collective = (self.world > 1) if collective is None else bool(collective)
+        self.part = [int(v) for v in part]
+        self.npanels = int(npanels)
+        my_p = np.asarray(my_p, np.int64) - int(my_p[0])
+        my_i = np.asarray(my_i, np.int64)
+        rows = len(my_p) - 1
+        assert rows == self.part[rank + 1] - self.part[rank]
+        col_counts = np.bincount(my_i, minlength=ncols).astype(np.int64)
+        col_counts = self._reduce_sum(col_counts, device)
+        prefix = np.concatenate([[0], np.cumsum(col_counts)])
+        cuts = [0]
+        for c in range(1, self.npanels):
+            k = int(np.searchsorted(prefix, prefix[-1] * c / self.npanels, side="left"))
+            cuts.append(min(max(k, cuts[-1]), ncols))
+        cuts.append(ncols)
+        self.cuts = cuts
+        pid = np.searchsorted(np.asarray(cuts[1:-1], np.int64), my_i, side="right")       # panel of every entry
+        self.perm = np.argsort(pid, kind="stable")
+        ends = np.cumsum(np.bincount(pid, minlength=self.npanels))
+        self.piece = [(int(ends[c - 1]) if c else 0, int(ends[c])) for c in range(self.npanels)]
+        row_of = np.repeat(np.arange(rows, dtype=np.int64), np.diff(my_p))
+        n = self.part[-1]
+        self.panel_p, self.panel_nnz, self.offs, self.counts = [], [], [], []
+        blocks = [self.part[r + 1] - self.part[r] for r in range(self.world)]
+        for c in range(self.npanels):
+            mine = np.bincount(row_of[pid == c], minlength=rows).astype(np.int64)
+            whole = torch.empty(n, dtype=torch.int64, device=device if self._on_device() else "cpu")
+            if self.collective:
+                all_gather_in_place(dist, torch, torch.from_numpy(mine).to(whole.device), whole, self.part[:-1], blocks, rank)
+            else:
+                whole.copy_(torch.from_numpy(mine))
+            pp = np.concatenate([[0], np.cumsum(whole.cpu().numpy())]).astype(np.int64)
+            self.panel_p.append(pp)
+            self.panel_nnz.append(int(pp[-1]))
+            self.offs.append([int(pp[self.part[r]]) for r in range(self.world)])
+            self.counts.append([int(pp[self.part[r + 1]] - pp[self.part[r]]) for r in range(self.world)])
+            assert self.counts[c][rank] == self.piece[c][1] - self.piece[c][0]
+        self.moved = sum(self.panel_nnz)                    # entries one pass over all panels moves: nnz(B)
+
+    def _on_device(self):
+        return self.collective and self.dist.get_backend() == "nccl"
+
+    def _reduce_sum(self, a, device):
+        if not self.collective:
+            return a
+        t = self.torch.from_numpy(a).to(device if self._on_device() else "cpu")
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    def gather(self, c, my_i_perm, my_x_perm, out_i, out_x):
+        """Panel c: my_*_perm are the block's entries in piece order, out_* receive panel_nnz[c] entries."""
+        a, b = self.piece[c]
+        nz = self.panel_nnz[c]
+        for mine, out in ((my_i_perm[a:b], out_i[:nz]), (my_x_perm[a:b], out_x[:nz])):
+            if not self.collective:
+                out.copy_(mine)
+            else:
+                all_gather_in_place(self.dist, self.torch, mine, out, self.offs[c], self.counts[c], self.rank)
 
 
 class VectorBlockExchange:

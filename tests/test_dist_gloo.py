@@ -258,3 +258,66 @@ def test_pieces_of_unequal_length_land_in_place_on_three_ranks(tmp_path):
         got = np.load(tmp_path / f"u{r}.npz")
         assert np.array_equal(got["out"], want)
         assert np.array_equal(got["gi"], want) and np.array_equal(got["gv"], want * 0.5)
+
+
+def _worker_panels(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from graphblas_amd import gen, Matrix, Type
+    from graphblas_amd.dist import ColumnPanelExchange
+    from oracle import oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A = gen.rmat(9, 8, seed=42, values="int")
+    n = A.nrows
+    rf = row_flops(A.p, A.i)
+    part = split_by_flops(np.concatenate([[0], np.cumsum(rf)]), 0, n, world)
+    lo, hi = part[rank], part[rank + 1]
+    e0, e1 = int(A.p[lo]), int(A.p[hi])
+    npanels = 3
+    # the exchange is set up from this rank's own block only
+    xc = ColumnPanelExchange(dist, torch, part, rank, n, A.p[lo:hi + 1], A.i[e0:e1], npanels, torch.device("cpu"))
+    my_i = torch.from_numpy(A.i[e0:e1][xc.perm].copy()); my_x = torch.from_numpy(A.x[e0:e1][xc.perm].copy())
+    assert xc.cuts[0] == 0 and xc.cuts[-1] == n and sum(xc.panel_nnz) == A.nvals
+    assert max(xc.panel_nnz) < 0.6 * A.nvals                          # a rank holds a panel, not the matrix
+    room = max(xc.panel_nnz)
+    Bi = torch.empty(room, dtype=torch.int64); Bx = torch.empty(room, dtype=torch.float64)
+    p = (A.p[lo:hi + 1] - A.p[lo]).astype(np.int64)
+    Ablk = Matrix(n, hi - lo, Type.FP64, A.sparsity, False, p=p, i=A.i[e0:e1], x=A.x[e0:e1])
+    S = A.to_scipy()
+    rows = [[] for _ in range(hi - lo)]
+    for c in range(npanels):
+        Bi.fill_(-1)
+        xc.gather(c, my_i, my_x, Bi, Bx)
+        nz = xc.panel_nnz[c]
+        Sc = S[:, xc.cuts[c]:xc.cuts[c + 1]].tocsr(); Sc.sort_indices()       # the panel, from the whole matrix
+        assert np.array_equal(xc.panel_p[c], Sc.indptr) and np.array_equal(Bi.numpy()[:nz], Sc.indices + xc.cuts[c])
+        assert np.array_equal(Bx.numpy()[:nz], Sc.data)
+        Bc = Matrix(n, n, Type.FP64, A.sparsity, False, p=xc.panel_p[c], i=Bi.numpy()[:nz].copy(), x=Bx.numpy()[:nz].copy())
+        Cc = oracle.saxpy3(None, False, False, Bc, Ablk, "PLUS_TIMES_FP64", wait=True)       # C(I, J_c), CSR
+        assert Cc.nvals == 0 or (Cc.i.min() >= xc.cuts[c] and Cc.i.max() < xc.cuts[c + 1])
+        for r in range(hi - lo):
+            rows[r].append((Cc.i[Cc.p[r]:Cc.p[r + 1]], Cc.x[Cc.p[r]:Cc.p[r + 1]]))
+    ci = [np.concatenate([q[0] for q in r]) for r in rows]; cx = [np.concatenate([q[1] for q in r]) for r in rows]
+    np.savez(os.path.join(outdir, f"c{rank}.npz"), p=np.concatenate([[0], np.cumsum([len(v) for v in ci])]),
+             i=np.concatenate(ci), x=np.concatenate(cx), lo=lo, hi=hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_column_panels_of_B_give_the_same_product_on_two_ranks(tmp_path):
+    """B exchanged one column panel at a time (for a B that does not fit whole on every rank): each rank sets the
+    exchange up from its own row block, every gathered panel equals that column range of the whole matrix, and the
+    panels of C(I, J_c) = A(I,:) B(:, J_c) laid side by side are the rows of the one-process product."""
+    import torch.multiprocessing as mp
+    from graphblas_amd import gen
+    from oracle import oracle
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_panels, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    A = gen.rmat(9, 8, seed=42, values="int")
+    want = oracle.saxpy3(None, False, False, A, A, "PLUS_TIMES_FP64", wait=True)
+    blocks = [np.load(tmp_path / f"c{r}.npz") for r in range(world)]
+    assert blocks[0]["lo"] == 0 and blocks[0]["hi"] == blocks[1]["lo"] and blocks[1]["hi"] == A.nrows
+    p = np.concatenate([blocks[0]["p"], blocks[1]["p"][1:] + blocks[0]["p"][-1]])
+    i = np.concatenate([b["i"] for b in blocks]); x = np.concatenate([b["x"] for b in blocks])
+    assert np.array_equal(p, want.p) and np.array_equal(i, want.i) and np.array_equal(x, want.x)

@@ -40,3 +40,30 @@ def test_two_ranks_on_one_device_agree_with_one_rank(what, keys):
         assert one[k] == two[k], (k, one[k], two[k])
     if what == "bfs":
         assert [lv["found"] for lv in one["levels"]] == [lv["found"] for lv in two["levels"]]
+
+
+def _spgemm_record(gpus, extra, env_extra):
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--scale", "14", "--steps", "1", "--warmup", "1",
+                        "--chunk-flops", "2e7", "--no-cpu-baseline", "--no-spmv"] + extra,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_column_panels_of_B_give_the_product_of_the_whole_B():
+    """C = A*A with the right-hand operand exchanged one column panel at a time (bench.py --b-panels): every panel
+    product passes the row-sum check against the host, and the panels together hold as many entries as the product
+    against the gathered B -- with one rank over RCCL, and with two ranks on device 0 over gloo."""
+    whole = _spgemm_record(1, [], {"GBA_BENCH_FORCE_DIST": "1"})
+    assert whole["verified"] is True
+    for gpus, env in ((1, {"GBA_BENCH_FORCE_DIST": "1"}), (2, {"GBA_BENCH_REHEARSE": "1"})):
+        cut = _spgemm_record(gpus, ["--b-panels", "3"], env)
+        assert cut["verified"] is True and cut["n_gpus"] == gpus
+        assert cut["config"]["nnz_C"] == whole["config"]["nnz_C"]
+        assert "3columnpanelsB" in cut["config"]["parallelism"]
+        assert cut["verification"]["chunks"] >= 3
