@@ -1651,6 +1651,7 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
 #endif
                               ;
         int64_t *__restrict__ my_scratch = scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg;
+        GBA_TICK(tkt0);
         if (by_table) {
             const int32_t *__restrict__ Ai = A.i32;
             const int64_t cells = (npanels + 1) * deg;
@@ -1667,6 +1668,8 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
             }
             __syncthreads();
         }
+        GBA_TICK(tkt1);
+        GBA_TOCK(&Q, 6, tkt0, tkt1);
         for (int64_t p = 0; p < npanels; p++) {
             const int64_t base = p * SYM_PANEL_WIDTH;
             const int64_t pend = (p == npanels - 1) ? PANEL_INF : base + SYM_PANEL_WIDTH;
@@ -1690,14 +1693,19 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                 panel_walk<SYM_PANEL_UNROLL, SYM_PANEL_PIPELINE>(A, B, pB0, deg, 0, pend, PANEL_INF, p == 0, pc, &Q, no_load, mark_products, false);
             // count in index order: each thread owns SYM_WORDS_PER_THREAD consecutive words (its slice); the packed
             // sum carries the entries (low 21 bits: a panel has at most 2^20) and the non-empty words (above)
+            GBA_TICK(tks0);
             const int w0 = tid * SYM_WORDS_PER_THREAD;
             uint32_t *mine_bm = bm + tid * SYM_SLICE_STRIDE;
-            uint64_t both = 0;
+            // first walk over the slice, last word first: the entries, and which words hold any (bit q of held = word q;
+            // held = 2 * held + (x != 0) is one add-with-carry)
+            uint32_t entries = 0, held = 0;
 #pragma unroll 8
-            for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) {
+            for (int q = SYM_WORDS_PER_THREAD - 1; q >= 0; q--) {
                 const uint32_t x = mine_bm[q];
-                both += (uint64_t)__builtin_popcount(x) + ((uint64_t)(x != 0u) << 21);
+                entries += (uint32_t)__builtin_popcount(x);
+                held = held + held + (x != 0u ? 1u : 0u);
             }
+            const uint64_t both = (uint64_t)entries + ((uint64_t)__builtin_popcount(held) << 21);
             const int mine = (int)(both & 0x1fffffu);
             uint64_t incl2 = both;
 #pragma unroll
@@ -1711,9 +1719,9 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
             const int total = (int)(total2 & 0x1fffffu), nztotal = (int)(total2 >> 21);
             const int nzlo = (int)(excl2 >> 21);                // non-empty words of the panel before this thread's slice
             const int64_t lo = seen + (int64_t)(excl2 & 0x1fffffu);   // entries before this thread's slice
-            const int64_t m = lo / NUM_PANEL_FIT + 1;       // the next multiple to be crossed
-            // second walk over the slice: the boundary that falls into it, if any; the pattern itself, for the numeric
-            // sweep that ranks instead of hashing -- the non-empty words as (word number, bits) pairs in index order,
+            const int64_t m = (int64_t)((uint32_t)lo / (uint32_t)NUM_PANEL_FIT) + 1;       // the next multiple to be crossed (cvlen < 2^31: the indices are read from a 32-bit copy)
+            // second walk, over the non-empty words of the slice only: the boundary that falls into it, if any; the
+            // pattern itself, for the numeric sweep that ranks instead of hashing -- the non-empty words as (word number, bits) pairs in index order,
             // a thread's words behind those of the thread before, so the lanes of a wave write neighbouring places;
             // and the slice is left clean (own slice only: no barrier needed)
             if (mine) {
@@ -1721,10 +1729,7 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                 int nzb = 0;                                // non-empty words of the slice so far
                 uint2 *out = pw ? pw + wseen + nzlo : nullptr;
                 const uint32_t wid0 = (uint32_t)(base >> 5) + (uint32_t)w0;
-#pragma unroll 4
-                for (int q = 0; q < SYM_WORDS_PER_THREAD; q++) {
-                    const uint32_t xq = mine_bm[q];
-                    if (xq == 0u) continue;
+                auto visit = [&](int q, uint32_t xq) {
                     mine_bm[q] = 0u;
                     if (r > 0) {
                         const int pcq = __builtin_popcount(xq);
@@ -1740,6 +1745,10 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                     }
                     if (out) out[nzb] = make_uint2(wid0 + (uint32_t)q, xq);
                     nzb++;
+                };
+                for (uint32_t t = held; t; t &= t - 1u) {    // the words that hold something, in index order
+                    const int q = __builtin_ctz(t);
+                    visit(q, mine_bm[q]);
                 }
             }
             if (pw) wseen += nztotal;
@@ -1747,6 +1756,8 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
             const int more = Q.more;
             pc.swap();
             __syncthreads();
+            GBA_TICK(tks1);
+            GBA_TOCK(&Q, 5, tks0, tks1);
             if (!more) break;
         }
         if (tid == 0) {
@@ -2448,7 +2459,7 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
             GBA_HIP(hipMemcpyFromSymbol(tk, HIP_SYMBOL(g_sym_ticks), sizeof(tk)));
             GBA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sym_ticks), zero, sizeof(zero)));
             fprintf(stderr, "[gba] symbolic panel kernel, vectors %lld; 10 ns ticks summed over workgroups: search %llu (+wait %llu) prefix %llu "
-                    "products %llu (+wait %llu) kernel %llu\n", (long long)sb.count[BIN_GLOBAL], tk[0], tk[1], tk[2], tk[3], tk[4], tk[7]);
+                    "products %llu (+wait %llu) count passes %llu table %llu kernel %llu\n", (long long)sb.count[BIN_GLOBAL], tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6], tk[7]);
         }
 #endif
     } else if (sb.count[BIN_GLOBAL] > 0) {
