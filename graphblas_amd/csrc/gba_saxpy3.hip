@@ -1023,6 +1023,8 @@ static constexpr int NUM_PANEL_SLOTS = 11 * PANEL_THREADS;                      
 static constexpr int NUM_PANEL_TARGET = 3000;                         // distinct indices aimed at per panel (no boundaries known)
 static constexpr int NUM_PANEL_FIT = NUM_PANEL_SLOTS / 4 * 3;                            // entries between two recorded boundaries: three quarters of the slots
 static constexpr int SYM_WORDS_PER_THREAD = SYM_PANEL_WORDS / PANEL_THREADS;
+static constexpr int SYM_HASH_BITS = (SYM_PANEL_WORDS == 32768) ? 15 : 14;       // the bitmap's words as a hash set of a light vector
+static_assert((1 << SYM_HASH_BITS) == SYM_PANEL_WORDS && NUM_PANEL_FIT * 3 <= SYM_PANEL_WORDS, "the hash set stays under a third full");
 // The bitmap is stored with one word of padding after every thread's slice: slice t starts at word t * (SWPT + 1).
 // In the passes that count, list and clear the bitmap every thread walks its own slice; without the padding the
 // lanes of a wave are 32 words apart and fall on the same LDS banks (an 8-way conflict on every 16-byte access),
@@ -1617,11 +1619,13 @@ __global__ void __launch_bounds__(PANEL_THREADS)
 sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpView B, MaskView M, int64_t cvlen,
                  int64_t maxdeg, int64_t *__restrict__ scratch, unsigned long long *__restrict__ next,
                  int64_t *__restrict__ cnt, const int64_t *__restrict__ bstart, int64_t *__restrict__ bounds,
-                 const int64_t *__restrict__ pstart, uint2 *__restrict__ pwords, int64_t *__restrict__ wbounds) {
+                 const int64_t *__restrict__ pstart, uint2 *__restrict__ pwords, int64_t *__restrict__ wbounds,
+                 const int64_t *__restrict__ vflops) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *bm = reinterpret_cast<uint32_t *>(smem);
     __shared__ PanelSegs Q;
     __shared__ int64_t row;
+    __shared__ uint32_t fresh_total;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int w = tid; w < SYM_PANEL_LDS_WORDS; w += PANEL_THREADS) bm[w] = 0;
     if (tid == 0) { Q.nseg = 0; Q.overflow = 0; }
@@ -1642,6 +1646,51 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
         uint2 *pw = pwords ? pwords + pstart[j] : nullptr;  // where the non-empty bitmap words of C(:,j) are written, in index order
         int64_t *jw = pwords ? wbounds + bstart[j] : nullptr;   // and where the word of every boundary stands in that list
         int64_t seen = 0, wseen = 0;                        // entries / non-empty words of C(:,j) below the current panel
+        int64_t *__restrict__ my_scratch = scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg;
+#ifndef GBA_SYM_NO_SMALL
+        // A vector that cannot reach the first boundary (fewer multiply-adds than a stretch has entries) needs its
+        // count only, and the sweeps over the whole index range would cost it far more than its products: one walk
+        // over all its products instead, the indices hashed into the words of the bitmap (open addressing, i + 1 as
+        // the key, at most a quarter full).  No pattern words are recorded: its one stretch is hashed by the
+        // numeric sweep as well.
+        if (vflops && vflops[j] < (int64_t)NUM_PANEL_FIT && 2 * deg <= (int64_t)PANEL_SCRATCH_ARRAYS * maxdeg) {
+            for (int64_t t = tid; t < deg; t += PANEL_THREADS) {
+                const int64_t k = B.i[pB0 + t];
+                my_scratch[t] = A.p[k]; my_scratch[deg + t] = A.p[k + 1];
+            }
+            if (tid == 0) { Q.more = 0; fresh_total = 0u; }
+            __syncthreads();
+            uint32_t fresh = 0;
+            auto no_load = [](int32_t, int64_t, int64_t) { return 0; };
+            auto insert_products =
+                [&](const int32_t (&i)[SYM_PANEL_UNROLL], const int (&)[SYM_PANEL_UNROLL], const bool (&ok)[SYM_PANEL_UNROLL]) {
+#pragma unroll
+                    for (int u = 0; u < SYM_PANEL_UNROLL; u++) {
+                        if (!ok[u]) continue;
+                        if constexpr (MASKED) { if (!mask_allows(M, i[u], j)) continue; }
+                        const uint32_t key = (uint32_t)i[u] + 1u;
+                        uint32_t h = (key * 2654435761u) >> (32 - SYM_HASH_BITS);
+                        while (true) {
+                            const uint32_t old = atomicCAS(&bm[h], 0u, key);
+                            if (old == 0u) { fresh++; break; }
+                            if (old == key) break;
+                            h = (h + 1u) & (uint32_t)(SYM_PANEL_WORDS - 1);
+                        }
+                    }
+                };
+            panel_walk_table<SYM_PANEL_UNROLL, SYM_PANEL_PIPELINE>(A, pB0, deg, 0, PANEL_INF, my_scratch, 2, 0, 1, &Q, no_load, insert_products, false);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) fresh += __shfl_down(fresh, d, 64);
+            if (lane == 0 && fresh) atomicAdd(&fresh_total, fresh);
+            for (int w = tid; w < SYM_PANEL_WORDS; w += PANEL_THREADS) bm[w] = 0u;
+            __syncthreads();
+            if (tid == 0) {
+                cnt[j] = (int64_t)fresh_total;
+                if (jw) jw[0] = 0;                          // no word list: the numeric sweep hashes the vector
+            }
+            continue;
+        }
+#endif
         // Few neighbours: where every neighbour's list crosses the panel edges (multiples of the panel width) is
         // looked up once, by independent bisections, and the sweeps read their runs from that table
         // (panel_walk_table) instead of advancing cursors with the group search.
@@ -1650,7 +1699,6 @@ sym_panel_kernel(int64_t nlist, const int64_t *__restrict__ list, SpView A, SpVi
                               && false
 #endif
                               ;
-        int64_t *__restrict__ my_scratch = scratch + (int64_t)blockIdx.x * PANEL_SCRATCH_ARRAYS * maxdeg;
         GBA_TICK(tkt0);
         if (by_table) {
             const int32_t *__restrict__ Ai = A.i32;
@@ -2450,7 +2498,8 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
         GBA_OK(order_by_work_desc(sb.count[BIN_GLOBAL], sb.list(BIN_GLOBAL), P.vflops, &order));
         hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(PANEL_THREADS), lds, st,
                            sb.count[BIN_GLOBAL], order.as<int64_t>(), P.A, P.B, P.M, P.cvlen, P.maxdeg,
-                           scratch.as<int64_t>(), next.as<unsigned long long>(), cnt, P.bstart, P.bounds, P.pstart, P.pwords, P.wbounds);
+                           scratch.as<int64_t>(), next.as<unsigned long long>(), cnt, P.bstart, P.bounds, P.pstart, P.pwords, P.wbounds,
+                           P.vflops);
         GBA_HIP(hipGetLastError());
         GBA_HIP(hipStreamSynchronize(st));
 #ifdef GBA_PANEL_TICKS

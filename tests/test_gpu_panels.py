@@ -186,6 +186,36 @@ def test_heavy_vectors_with_few_neighbours(gba, sr):
     assert_same(got, want, exact=True, what=sr)
 
 
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("shape", ["many_short_lists", "few_long_lists"])
+def test_vectors_below_one_stretch_are_counted_in_one_walk(gba, shape, masked):
+    """Vectors of 2049 .. 8447 multiply-adds go through the panel kernels but cannot reach a boundary: the symbolic
+    kernel counts them in one walk with a hash set instead of bitmap sweeps, and records no word list.  Indices
+    collide often (few rows), and a vector just above the limit takes the sweeps next to them."""
+    if shape == "many_short_lists":
+        degs = [300, 450, 513, 600, 690] * 8                # (more than 16 384 entries in B: not the one-launch road of small products)
+        As, Bs = _few_long_neighbours(5_000, degs, 12, seed=21, nhubs=700)
+    else:
+        degs = [2, 3, 4, 5, 9]
+        As, Bs = _few_long_neighbours(9_000, degs, 1_900, seed=22, nhubs=60)
+    A, B = _mat(As), _mat(Bs)
+    dA, dB = A.to_device(), B.to_device()
+    mw, fl = gba.AxB_saxpy3_flopcount(None, False, dA, dB)
+    dA.free(); dB.free()
+    per = np.diff(fl)
+    assert ((per > 2048) & (per < 8448)).sum() >= 3, per
+    M = None
+    if masked:
+        Ms = sp.random(As.shape[0], len(degs), density=0.5, random_state=np.random.default_rng(23), format="csc")
+        Ms.data[:] = 1
+        M = _mat(Ms, Type.BOOL)
+    got, rep = _run(gba, A, B, "PLUS_TIMES_FP64", M, False, True)
+    want = oracle.saxpy3(M, False, True, A, B, "PLUS_TIMES_FP64")
+    if not masked:
+        assert rep.bin_vectors[3] >= 3, list(rep.bin_vectors)       # they did take the panel kernels
+    assert_same(got, want, exact=True, what=f"{shape} masked={masked} flops={per.tolist()}")
+
+
 def test_few_neighbours_split_into_tasks(gba):
     """A vector of more than 4e6 multiply-adds is split, and a later task starts its sweep in the middle of the
     lists: the first search is for the task's first index."""
