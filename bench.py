@@ -409,7 +409,7 @@ def spmv_leg(g, torch, A, Bp, Bi, Bx, dev, args, iters=20):
             if name.startswith("dot_tile_kernel") and name.rstrip().endswith(", 0>"):
                 out["traffic"] = k.get("traffic")
                 out["lds_bank_conflict_frac"] = k.get("lds_bank_conflict_frac")
-                out["counters_from"] = "profiles/ " + str(rec.get("round", ""))
+                out["counters_from"] = "profiles/" + str(rec.get("round", "")) + "_rmat22_counters_per_kernel.csv"
     except (OSError, ValueError, KeyError):
         pass
     return out
@@ -429,7 +429,7 @@ def measured_counters(workload, kernel):
                         "wave_issue_frac", "wave_wait_frac"):
                 if key in rec:
                     out[key] = rec[key]
-            out["counters_from"] = "profiles/ " + str(rec.get("round", ""))
+            out["counters_from"] = "profiles/" + str(rec.get("round", "")) + "_rmat22_counters_per_kernel.csv"
     except (OSError, ValueError, KeyError):
         pass
     return out
