@@ -2531,6 +2531,10 @@ static gba_info run_symbolic(Saxpy3Plan &P, int64_t *cnt) {
     return GBA_SUCCESS;
 }
 
+static gba_info saxpy3_long_vectors(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
+                                    const gba_matrix *A, const gba_matrix *B, const Canon &c,
+                                    int axb_method, int do_sort, bool *mask_applied, gba_report *rep, bool may_discard_mask);
+
 gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
                 const gba_matrix *A, const gba_matrix *B, const Canon &c,
                 int axb_method, int do_sort, bool *mask_applied, gba_report *rep, bool may_discard_mask) {
@@ -2540,7 +2544,8 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxpy3 on device needs sparse A and B (got sparsity %d, %d)", A->sparsity, B->sparsity);
     if (A->vdim != B->vlen) GBA_FAIL(GBA_DIMENSION_MISMATCH, "saxpy3: A->vdim %ld != B->vlen %ld", (long)A->vdim, (long)B->vlen);
     if (A->nzombies || B->nzombies) GBA_FAIL(GBA_INVALID_OBJECT, "saxpy3: operands have zombies");
-    if (A->vlen >= (int64_t)0x7fffffff) GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxpy3: vector length >= 2^31");
+    if (A->vlen >= (int64_t)0x7fffffff)                    // the kernels keep indices in 32 bits: see below
+        return saxpy3_long_vectors(C, M, Mask_comp, Mask_struct, A, B, c, axb_method, do_sort, mask_applied, rep, may_discard_mask);
     if (M && (M->vlen != A->vlen || M->vdim != B->vdim)) GBA_FAIL(GBA_DIMENSION_MISMATCH, "saxpy3: mask dimensions");
     hipStream_t st = ctx().stream;
     DevBuf sorted_i, sorted_x;
@@ -2908,6 +2913,129 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
     C->jumbled = true;      // hash bins emit in table order (the reference leaves C jumbled too)
     if (mask_applied) *mask_applied = (M != nullptr);
     if (do_sort) GBA_OK(matrix_wait(C));
+    return GBA_SUCCESS;
+}
+
+// ---- vectors of 2^31 indices or more -----------------------------------------------------------------
+// The kernels above hold indices of C in 32 bits (hash keys, bitmap offsets, the narrowed copy of A's indices); the
+// CPU method has no such limit (Source/GB_AxB_saxpy3.c:120 takes any vlen).  A matrix that long holds few of its
+// indices, and only indices that occur in A can occur in C: the distinct indices of A are ranked (one sort), A and
+// the mask are rewritten in ranks -- entries of the mask at other indices can never meet a product and are dropped --
+// the product is formed over the ranks, and the result's ranks are turned back into indices.  Ranking keeps the
+// order, so sorted vectors stay sorted.
+__global__ void __launch_bounds__(256)
+rank_of_index_kernel(int64_t n, const int64_t *__restrict__ idx, const int64_t *__restrict__ U, int64_t nu,
+                     int64_t *__restrict__ out) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < n; e += stride) {
+        const int64_t v = idx[e];
+        int64_t a = 0, b = nu;
+        while (a < b) { const int64_t m = (a + b) >> 1; if (U[m] < v) a = m + 1; else b = m; }
+        out[e] = (a < nu && U[a] == v) ? a : -1;          // -1: not among the ranked indices
+    }
+}
+
+__global__ void __launch_bounds__(256)
+index_of_rank_kernel(int64_t n, int64_t *__restrict__ idx, const int64_t *__restrict__ U) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < n; e += stride) {
+        const int64_t r = idx[e];
+        idx[e] = (r >= 0) ? U[r] : -U[-r - 2] - 2;        // (a zombie keeps its flipped form, GB_FLIP (i) = -i - 2)
+    }
+}
+
+// the ranked entries of every vector of the mask, kept in order: a wavefront per vector; FILL = false counts
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+ranked_mask_kernel(int64_t nvec, const int64_t *__restrict__ Mp, const int64_t *__restrict__ rank,
+                   const unsigned char *__restrict__ Mx, int msize, int64_t *__restrict__ Rp, int64_t *__restrict__ Ri,
+                   unsigned char *__restrict__ Rx) {
+    const int lane = threadIdx.x & 63;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6, p0 = Mp[0];
+    for (; j < nvec; j += stride) {
+        const int64_t m0 = Mp[j], m1 = Mp[j + 1];
+        int64_t out = FILL ? Rp[j] : 0;
+        for (int64_t q = m0; q < m1; q += 64) {
+            const int64_t p = q + lane;
+            const int64_t r = (p < m1) ? rank[p - p0] : -1;
+            const unsigned long long m = __ballot(r >= 0);
+            if (FILL && r >= 0) {
+                const int64_t w = out + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                Ri[w] = r;
+                if (Rx) for (int b = 0; b < msize; b++) Rx[w * msize + b] = Mx[p * msize + b];
+            }
+            out += __builtin_popcountll(m);
+        }
+        if (!FILL && lane == 0) Rp[j] = out;
+    }
+}
+
+static gba_info saxpy3_long_vectors(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
+                                    const gba_matrix *A, const gba_matrix *B, const Canon &c,
+                                    int axb_method, int do_sort, bool *mask_applied, gba_report *rep, bool may_discard_mask) {
+    hipStream_t st = ctx().stream;
+    if (M && !is_sparse(M)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxpy3: a bitmap or full mask over vectors of 2^31 indices or more");
+    if (M && (M->vlen != A->vlen || M->vdim != B->vdim)) GBA_FAIL(GBA_DIMENSION_MISMATCH, "saxpy3: mask dimensions");
+    if (M && (M->nzombies || M->jumbled)) GBA_FAIL(GBA_INVALID_OBJECT, "saxpy3: the mask has pending work");
+    int64_t a0 = 0, a1 = 0;
+    GBA_OK(dev_read_i64(A->p, &a0));
+    GBA_OK(dev_read_i64(A->p + A->nvec, &a1));
+    const int64_t anz = a1 - a0;
+    int bits = 1;
+    while (bits < 63 && ((int64_t)1 << bits) < A->vlen) bits++;
+    DevBuf U, Ar;
+    int64_t nu = 0;
+    GBA_OK(distinct_sorted(A->i + a0, anz, bits, &U, &nu));
+    if (nu >= (int64_t)0x7fffffff) GBA_FAIL(GBA_NOT_IMPLEMENTED, "saxpy3: %ld distinct indices in A", (long)nu);
+    GBA_OK(Ar.alloc((size_t)(anz > 0 ? anz : 1) * 8));
+    auto grid = [](int64_t n) { int64_t b = ceil_div(n, 256); if (b > 16384) b = 16384; if (b < 1) b = 1; return dim3((unsigned)b); };
+    if (anz > 0) hipLaunchKernelGGL(rank_of_index_kernel, grid(anz), dim3(256), 0, st, anz, A->i + a0, U.as<int64_t>(), nu, Ar.as<int64_t>());
+    GBA_HIP(hipGetLastError());
+    gba_matrix A2 = *A;
+    A2.vlen = nu > 0 ? nu : 1;
+    A2.i = Ar.as<int64_t>() - a0;                          // (indexed by the same absolute offsets as A->i)
+    gba_matrix M2;
+    DevBuf Mr, Rp, Ri, Rx;
+    if (M) {
+        int64_t m0 = 0, m1 = 0;
+        GBA_OK(dev_read_i64(M->p, &m0));
+        GBA_OK(dev_read_i64(M->p + M->nvec, &m1));
+        const int64_t mnz = m1 - m0, nvec = M->nvec;
+        const int msize = (int)type_size(M->type);
+        const bool valued = !Mask_struct && !M->iso && M->x;
+        GBA_OK(Mr.alloc((size_t)(mnz > 0 ? mnz : 1) * 8));
+        if (mnz > 0) hipLaunchKernelGGL(rank_of_index_kernel, grid(mnz), dim3(256), 0, st, mnz, M->i + m0, U.as<int64_t>(), nu, Mr.as<int64_t>());
+        GBA_OK(Rp.alloc((size_t)(nvec + 1) * 8));
+        GBA_HIP(hipMemsetAsync(Rp.p, 0, (size_t)(nvec + 1) * 8, st));
+        const dim3 wgrid = grid(nvec * 64);
+        if (nvec > 0) hipLaunchKernelGGL(ranked_mask_kernel<false>, wgrid, dim3(256), 0, st, nvec, M->p, Mr.as<int64_t>(),
+                                         (const unsigned char *)nullptr, msize, Rp.as<int64_t>(), (int64_t *)nullptr, (unsigned char *)nullptr);
+        GBA_HIP(hipGetLastError());
+        GBA_OK(dev_cumsum_i64(Rp.as<int64_t>(), nvec, st));
+        int64_t rnz = 0;
+        GBA_OK(dev_read_i64(Rp.as<int64_t>() + nvec, &rnz));
+        GBA_OK(Ri.alloc((size_t)(rnz > 0 ? rnz : 1) * 8));
+        if (valued) GBA_OK(Rx.alloc((size_t)(rnz > 0 ? rnz : 1) * msize));
+        if (nvec > 0 && rnz > 0)
+            hipLaunchKernelGGL(ranked_mask_kernel<true>, wgrid, dim3(256), 0, st, nvec, M->p, Mr.as<int64_t>(),
+                               reinterpret_cast<const unsigned char *>(M->x), msize, Rp.as<int64_t>(), Ri.as<int64_t>(),
+                               valued ? Rx.as<unsigned char>() : (unsigned char *)nullptr);
+        GBA_HIP(hipGetLastError());
+        M2 = *M;
+        M2.vlen = A2.vlen; M2.p = Rp.as<int64_t>(); M2.i = Ri.as<int64_t>(); M2.nvals = rnz;
+        if (valued) M2.x = Rx.p;                            // (an iso or structural mask keeps reading M's own value)
+    }
+    const gba_info info = saxpy3(C, M ? &M2 : nullptr, Mask_comp, Mask_struct, &A2, B, c, axb_method, do_sort, mask_applied, rep, may_discard_mask);
+    if (info != GBA_SUCCESS) return info;                   // (GBA_NO_VALUE: the caller multiplies again without the mask)
+    int64_t cnz = 0;
+    if (C->p) GBA_OK(dev_read_i64(C->p + C->nvec, &cnz));
+    if (cnz > 0) hipLaunchKernelGGL(index_of_rank_kernel, grid(cnz), dim3(256), 0, st, cnz, C->i, U.as<int64_t>());
+    GBA_HIP(hipGetLastError());
+    GBA_HIP(hipStreamSynchronize(st));                      // U is released on return
+    C->vlen = A->vlen;
     return GBA_SUCCESS;
 }
 

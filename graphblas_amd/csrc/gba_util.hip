@@ -248,6 +248,30 @@ static gba_info sort_long_vectors(gba_matrix *C, const int64_t *list, int64_t n,
     return GBA_SUCCESS;
 }
 
+// The distinct values among idx[0..n), ascending: one radix sort of a copy and one pass that keeps the first of
+// every run.  `bits` = significant bits of the values.
+gba_info distinct_sorted(const int64_t *idx, int64_t n, int bits, DevBuf *out, int64_t *count) {
+    hipStream_t st = ctx().stream;
+    *count = 0;
+    if (n >= ((int64_t)1 << 31)) GBA_FAIL(GBA_NOT_IMPLEMENTED, "%ld indices are too many for the device sort", (long)n);
+    GBA_OK(out->alloc((size_t)(n > 0 ? n : 1) * 8));
+    if (n == 0) return GBA_SUCCESS;
+    DevBuf sorted, tmp, cnt;
+    GBA_OK(sorted.alloc((size_t)n * 8));
+    GBA_OK(cnt.alloc(8));
+    size_t bytes = 0;
+    GBA_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, idx, sorted.as<int64_t>(), (int)n, 0, bits, st));
+    GBA_OK(tmp.alloc(bytes ? bytes : 1));
+    GBA_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, bytes, idx, sorted.as<int64_t>(), (int)n, 0, bits, st));
+    size_t bytes2 = 0;
+    GBA_HIP(hipcub::DeviceSelect::Unique(nullptr, bytes2, sorted.as<int64_t>(), out->as<int64_t>(), cnt.as<int64_t>(), (int)n, st));
+    DevBuf tmp2;
+    GBA_OK(tmp2.alloc(bytes2 ? bytes2 : 1));
+    GBA_HIP(hipcub::DeviceSelect::Unique(tmp2.p, bytes2, sorted.as<int64_t>(), out->as<int64_t>(), cnt.as<int64_t>(), (int)n, st));
+    GBA_OK(dev_read_i64(cnt.as<int64_t>(), count));           // (synchronises: the temporaries go back to the pool)
+    return GBA_SUCCESS;
+}
+
 gba_info matrix_wait(gba_matrix *C) {
     GBA_OK(require_init());
     if (!is_sparse(C)) { C->jumbled = false; return GBA_SUCCESS; }      // bitmap/full: nothing pending

@@ -360,7 +360,10 @@ gba_info gba_mxm_select(const gba_matrix *C, const gba_matrix *M, const gba_bino
  * dropping a costly sparse mask and applying it afterwards
  * (Source/GB_AxB_saxpy3_slice_balanced.c:377-393) is not reproduced, so GBA_NO_VALUE
  * is never returned, and axb_method (GUSTAVSON / HASH hints) does not change the
- * kernels -- every vector is routed by its own flop count.  vlen must be < 2^31. */
+ * kernels -- every vector is routed by its own flop count.  The kernels keep indices in 32 bits; operands with
+ * vlen >= 2^31 - 1 (Source/GB_AxB_saxpy3.c:120 has no limit) are multiplied over the ranks of the distinct indices
+ * that A holds (fewer than 2^31 - 1 of them, in fewer than 2^31 entries) and the result is renamed back; such a
+ * mask must be sparse. */
 gba_info gba_AxB_saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
                         const gba_matrix *A, const gba_matrix *B, const gba_semiring *semiring,
                         int32_t axb_method, int32_t do_sort, bool *mask_applied, gba_report *report);

@@ -282,3 +282,73 @@ def test_a_jumbled_operand_of_a_large_product(gba, side):
     assert got.nnz == want.nnz and (got != want).nnz == 0           # small integers: exact
     for d in (dA, dC, dD):
         d.free()
+
+
+def _long(S, rows, vlen, t=Type.FP64):
+    """The CSC matrix S (k rows) with row r renamed rows[r]: a matrix of vlen rows that holds few of its indices."""
+    S = S.tocsc(); S.sort_indices()
+    return Matrix(vlen, S.shape[1], t, Sparsity.SPARSE, True, p=S.indptr.astype(np.int64), i=rows[S.indices].astype(np.int64),
+                  x=S.data.astype(np.float64 if t == Type.FP64 else np.int8))
+
+
+def _triples(Mx):
+    """(col, index, value) of a host CSC Matrix, vectors sorted by index."""
+    col = np.repeat(np.arange(Mx.nvec), np.diff(Mx.p))
+    o = np.lexsort((Mx.i, col))
+    return col[o], Mx.i[o], np.asarray(Mx.x)[o]
+
+
+@pytest.mark.parametrize("mask", [None, "plain", "complemented", "valued"])
+@pytest.mark.parametrize("vlen", [2**31 - 1, 2**40])
+def test_vectors_of_2_31_indices_or_more(gba, vlen, mask):
+    """Source/GB_AxB_saxpy3.c:120 takes any vector length; the device kernels keep indices in 32 bits, so a longer
+    matrix is multiplied over the ranks of the indices it holds.  Expected: the same product formed on the host over
+    ranks (numpy unique + scipy) and renamed back; integer values, exact."""
+    rng = np.random.default_rng(77)
+    k, n, nrows = 400, 60, 3000
+    rows = np.sort(rng.choice(vlen, nrows, replace=False).astype(np.int64))
+    rows[-1] = vlen - 1                                              # the last index of the range is in use
+    As, Bs = _rand(nrows, k, 0.02, 78), _rand(k, n, 0.05, 79)
+    A, B = _long(As, rows, vlen), _csc(Bs)
+    M = Ms = None
+    if mask:
+        Ms = _rand(nrows, n, 0.3, 80, lo=0, hi=2)                    # values 0 and 1: a valued mask differs from a structural one
+        other = np.setdiff1d(rng.choice(vlen, 500).astype(np.int64), rows)           # mask entries where A holds nothing
+        extra = sp.csc_matrix((np.ones(len(other)), (np.arange(len(other)), rng.integers(0, n, len(other)))), shape=(len(other), n))
+        allrows = np.concatenate([rows, other]); order = np.argsort(allrows, kind="stable")
+        both = sp.vstack([Ms, extra]).tocsr()[order].tocsc()
+        M = _long(both, allrows[order], vlen, Type.INT8)
+    comp, struct = mask == "complemented", mask != "valued"
+    got, rep, applied = _run(gba, A, B, "PLUS_TIMES_FP64", M, comp, struct)
+    T = (As @ Bs).tocsc()
+    if mask:
+        keep = (Ms != 0) if not struct else sp.csc_matrix((np.ones(len(Ms.data)), Ms.indices, Ms.indptr), shape=Ms.shape)
+        keep = keep.astype(bool).toarray()
+        if comp:
+            keep = ~keep
+        T = sp.csc_matrix(np.where(keep & (T.toarray() != 0), T.toarray(), 0.0))
+    T.sort_indices()
+    want = _long(T, rows, vlen)
+    assert (got.vlen, got.vdim) == (vlen, n) and got.nvals == want.nvals
+    for g, w in zip(_triples(got), _triples(want)):
+        assert np.array_equal(g, w)
+
+
+def test_the_front_end_takes_vectors_of_2_40_indices(gba):
+    """gba_mxm with an accumulator into a C that holds entries, all three of 2^40 rows."""
+    rng = np.random.default_rng(91)
+    vlen, k, n, nrows = 2**40, 300, 40, 2000
+    rows = np.sort(rng.choice(vlen, nrows, replace=False).astype(np.int64))
+    As, Bs, Cs = _rand(nrows, k, 0.03, 92), _rand(k, n, 0.05, 93), _rand(nrows, n, 0.05, 94)
+    A, B, C0 = _long(As, rows, vlen), _csc(Bs), _long(Cs, rows, vlen)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    gba.mxm(dC, None, "PLUS_FP64", "PLUS_TIMES_FP64", dA, dB, None)
+    gba.matrix_wait(dC)
+    got = dC.to_host()
+    want = (Cs + As @ Bs).tocsc(); want.sort_indices()
+    want = _long(want, rows, vlen)
+    assert (got.vlen, got.vdim) == (vlen, n)
+    for g, w in zip(_triples(got), _triples(want)):
+        assert np.array_equal(g, w)
+    for d in (dA, dB, dC):
+        d.free()
