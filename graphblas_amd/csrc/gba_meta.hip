@@ -1007,6 +1007,31 @@ static gba_info mxm_driver_sparse_C(Call k, gba_report *report, bool select_only
     // hypersparse operands are given to the kernels in sparse form (a pointer array over every vector);
     // a hypersparse C is made hypersparse again at the end (mxm_driver)
     gba_matrix Msp, Asp, Bsp;
+    // The inner dimension listed by a hypersparse operand: the reference looks the vectors of such an operand up
+    // through its hyper-hash (Source/Shared/GB_hyper_hash_lookup.h:16) instead of holding a pointer per vector.
+    // Here the inner dimension is renamed: the operand whose vectors run over it keeps its nvec listed vectors and
+    // loses the list (vector q is the old h[q]); the indices of the other operand, which run over the same
+    // dimension, are replaced by their ranks in h, and its entries at indices the list does not hold -- they would
+    // meet an empty vector -- are dropped.  The product is the same, entry for entry, and nothing of size vdim is built.
+    gba_matrix Aren, Bren;
+    // (not for a multiplier that yields the inner index itself -- FIRSTJ, SECONDI --, and not for an operand that is
+    // also C, whose arrays are replaced below)
+    if (!select_only && !op_is_positional(k.semiring.mult) && !getenv("GBA_NO_HYPER_RENAME")) {
+        const bool a_vec_is_inner = (A_in->is_csc != k.A_transpose), b_vec_is_inner = (B_in->is_csc == k.B_transpose);
+        auto listed = [](const gba_matrix *X) { return is_hyper(X) && X->nvec > 0 && X->h && X->p; };
+        auto has_indices = [](const gba_matrix *X) { return is_sparse(X) || is_hyper(X); };
+        if (a_vec_is_inner && !b_vec_is_inner && listed(A_in) && has_indices(B_in) && A_in->p != C->p) {
+            if (A_in->vdim != B_in->vlen) GBA_FAIL(GBA_DIMENSION_MISMATCH, "inner dimensions %ld and %ld", (long)A_in->vdim, (long)B_in->vlen);
+            GBA_OK(ranked_copy(B_in, A_in->h, A_in->nvec, A_in->nvec, true, &Bren, ex.owned));
+            Aren = *A_in; Aren.h = nullptr; Aren.vdim = A_in->nvec; Aren.sparsity = GBA_SPARSE;
+            k.A_in = A_in = &Aren; k.B_in = B_in = &Bren;
+        } else if (b_vec_is_inner && !a_vec_is_inner && listed(B_in) && has_indices(A_in) && B_in->p != C->p) {
+            if (B_in->vdim != A_in->vlen) GBA_FAIL(GBA_DIMENSION_MISMATCH, "inner dimensions %ld and %ld", (long)A_in->vlen, (long)B_in->vdim);
+            GBA_OK(ranked_copy(A_in, B_in->h, B_in->nvec, B_in->nvec, true, &Aren, ex.owned));
+            Bren = *B_in; Bren.h = nullptr; Bren.vdim = B_in->nvec; Bren.sparsity = GBA_SPARSE;
+            k.A_in = A_in = &Aren; k.B_in = B_in = &Bren;
+        }
+    }
     if (k.M && is_hyper(k.M)) { GBA_OK(hyper_to_sparse(k.M, &Msp, ex.owned)); k.M = &Msp; }
     if (is_hyper(A_in)) { GBA_OK(hyper_to_sparse(A_in, &Asp, ex.owned)); k.A_in = A_in = &Asp; }
     if (is_hyper(B_in)) { GBA_OK(hyper_to_sparse(B_in, &Bsp, ex.owned)); k.B_in = B_in = &Bsp; }

@@ -2973,6 +2973,50 @@ ranked_mask_kernel(int64_t nvec, const int64_t *__restrict__ Mp, const int64_t *
     }
 }
 
+// X (sparse or hypersparse) with its indices replaced by their ranks in the ascending list U[0..nu) and the entries
+// at other indices (and zombies) dropped, the rest kept in order: new p and i, a compacted copy of x when the values
+// are wanted and X is not iso-valued (else X's own x), vlen = new_vlen; h, if any, is X's own.  The new arrays are
+// added to `owned`.
+gba_info ranked_copy(const gba_matrix *X, const int64_t *U, int64_t nu, int64_t new_vlen, bool with_values,
+                     gba_matrix *out, std::vector<void *> &owned) {
+    hipStream_t st = ctx().stream;
+    if (!is_sparse(X) && !is_hyper(X)) GBA_FAIL(GBA_INVALID_VALUE, "ranked_copy: sparsity %d", X->sparsity);
+    auto grid = [](int64_t n) { int64_t b = ceil_div(n, 256); if (b > 16384) b = 16384; if (b < 1) b = 1; return dim3((unsigned)b); };
+    int64_t m0 = 0, m1 = 0;
+    const int64_t nvec = X->nvec;
+    if (X->p) { GBA_OK(dev_read_i64(X->p, &m0)); GBA_OK(dev_read_i64(X->p + nvec, &m1)); }
+    const int64_t mnz = m1 - m0;
+    const int msize = (int)esize_of(X->type);
+    const bool valued = with_values && !X->iso && X->x;
+    DevBuf Mr, Rp, Ri, Rx;
+    GBA_OK(Mr.alloc((size_t)(mnz > 0 ? mnz : 1) * 8));
+    if (mnz > 0) hipLaunchKernelGGL(rank_of_index_kernel, grid(mnz), dim3(256), 0, st, mnz, X->i + m0, U, nu, Mr.as<int64_t>());
+    GBA_OK(Rp.alloc((size_t)(nvec + 1) * 8));
+    GBA_HIP(hipMemsetAsync(Rp.p, 0, (size_t)(nvec + 1) * 8, st));
+    const dim3 wgrid = grid(nvec * 64);
+    if (nvec > 0 && mnz > 0)
+        hipLaunchKernelGGL(ranked_mask_kernel<false>, wgrid, dim3(256), 0, st, nvec, X->p, Mr.as<int64_t>(),
+                           (const unsigned char *)nullptr, msize, Rp.as<int64_t>(), (int64_t *)nullptr, (unsigned char *)nullptr);
+    GBA_HIP(hipGetLastError());
+    GBA_OK(dev_cumsum_i64(Rp.as<int64_t>(), nvec, st));
+    int64_t rnz = 0;
+    GBA_OK(dev_read_i64(Rp.as<int64_t>() + nvec, &rnz));
+    GBA_OK(Ri.alloc((size_t)(rnz > 0 ? rnz : 1) * 8));
+    if (valued) GBA_OK(Rx.alloc((size_t)(rnz > 0 ? rnz : 1) * msize));
+    if (nvec > 0 && rnz > 0)
+        hipLaunchKernelGGL(ranked_mask_kernel<true>, wgrid, dim3(256), 0, st, nvec, X->p, Mr.as<int64_t>(),
+                           reinterpret_cast<const unsigned char *>(X->x), msize, Rp.as<int64_t>(), Ri.as<int64_t>(),
+                           valued ? Rx.as<unsigned char>() : (unsigned char *)nullptr);
+    GBA_HIP(hipGetLastError());
+    GBA_HIP(hipStreamSynchronize(st));                      // the ranks go back to the pool
+    *out = *X;
+    out->vlen = new_vlen; out->nvals = rnz; out->nzombies = 0;
+    out->p = reinterpret_cast<int64_t *>(Rp.release()); owned.push_back(out->p);
+    out->i = reinterpret_cast<int64_t *>(Ri.release()); owned.push_back(out->i);
+    if (valued) { out->x = Rx.release(); owned.push_back(out->x); }      // (an iso or structural X keeps reading its own value)
+    return GBA_SUCCESS;
+}
+
 static gba_info saxpy3_long_vectors(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_struct,
                                     const gba_matrix *A, const gba_matrix *B, const Canon &c,
                                     int axb_method, int do_sort, bool *mask_applied, gba_report *rep, bool may_discard_mask) {
@@ -2998,36 +3042,9 @@ static gba_info saxpy3_long_vectors(gba_matrix *C, const gba_matrix *M, bool Mas
     A2.vlen = nu > 0 ? nu : 1;
     A2.i = Ar.as<int64_t>() - a0;                          // (indexed by the same absolute offsets as A->i)
     gba_matrix M2;
-    DevBuf Mr, Rp, Ri, Rx;
-    if (M) {
-        int64_t m0 = 0, m1 = 0;
-        GBA_OK(dev_read_i64(M->p, &m0));
-        GBA_OK(dev_read_i64(M->p + M->nvec, &m1));
-        const int64_t mnz = m1 - m0, nvec = M->nvec;
-        const int msize = (int)type_size(M->type);
-        const bool valued = !Mask_struct && !M->iso && M->x;
-        GBA_OK(Mr.alloc((size_t)(mnz > 0 ? mnz : 1) * 8));
-        if (mnz > 0) hipLaunchKernelGGL(rank_of_index_kernel, grid(mnz), dim3(256), 0, st, mnz, M->i + m0, U.as<int64_t>(), nu, Mr.as<int64_t>());
-        GBA_OK(Rp.alloc((size_t)(nvec + 1) * 8));
-        GBA_HIP(hipMemsetAsync(Rp.p, 0, (size_t)(nvec + 1) * 8, st));
-        const dim3 wgrid = grid(nvec * 64);
-        if (nvec > 0) hipLaunchKernelGGL(ranked_mask_kernel<false>, wgrid, dim3(256), 0, st, nvec, M->p, Mr.as<int64_t>(),
-                                         (const unsigned char *)nullptr, msize, Rp.as<int64_t>(), (int64_t *)nullptr, (unsigned char *)nullptr);
-        GBA_HIP(hipGetLastError());
-        GBA_OK(dev_cumsum_i64(Rp.as<int64_t>(), nvec, st));
-        int64_t rnz = 0;
-        GBA_OK(dev_read_i64(Rp.as<int64_t>() + nvec, &rnz));
-        GBA_OK(Ri.alloc((size_t)(rnz > 0 ? rnz : 1) * 8));
-        if (valued) GBA_OK(Rx.alloc((size_t)(rnz > 0 ? rnz : 1) * msize));
-        if (nvec > 0 && rnz > 0)
-            hipLaunchKernelGGL(ranked_mask_kernel<true>, wgrid, dim3(256), 0, st, nvec, M->p, Mr.as<int64_t>(),
-                               reinterpret_cast<const unsigned char *>(M->x), msize, Rp.as<int64_t>(), Ri.as<int64_t>(),
-                               valued ? Rx.as<unsigned char>() : (unsigned char *)nullptr);
-        GBA_HIP(hipGetLastError());
-        M2 = *M;
-        M2.vlen = A2.vlen; M2.p = Rp.as<int64_t>(); M2.i = Ri.as<int64_t>(); M2.nvals = rnz;
-        if (valued) M2.x = Rx.p;                            // (an iso or structural mask keeps reading M's own value)
-    }
+    std::vector<void *> mine;
+    struct Free { std::vector<void *> &v; ~Free() { for (void *q : v) gba_free(q); } } free_mine{mine};
+    if (M) GBA_OK(ranked_copy(M, U.as<int64_t>(), nu, A2.vlen, !Mask_struct, &M2, mine));
     const gba_info info = saxpy3(C, M ? &M2 : nullptr, Mask_comp, Mask_struct, &A2, B, c, axb_method, do_sort, mask_applied, rep, may_discard_mask);
     if (info != GBA_SUCCESS) return info;                   // (GBA_NO_VALUE: the caller multiplies again without the mask)
     int64_t cnz = 0;

@@ -253,7 +253,10 @@ void     gba_matrix_free_content(gba_matrix *A);
  * input) and its sparsity/jumbled/nzombies fields describe the result, exactly
  * as GB_mxm leaves its C (Source/GB_mxm.c:149-221).
  * Operands and C of another built-in real type than the semiring's are cast
- * (Source/GB_casting.h rules); hypersparse A, B, M and C are accepted; a C
+ * (Source/GB_casting.h rules); hypersparse A, B, M and C are accepted (the
+ * inner dimension may have any size: the vectors a hypersparse operand lists
+ * are used as they are, Source/Shared/GB_hyper_hash_lookup.h:16; C and M up
+ * to 2^31 vectors); a C
  * that is hypersparse on entry is hypersparse on return, any other sparse
  * result stays sparse, unless C->hyper_switch asks for the reference's rule
  * (see gba_matrix).  A C that is iso-valued on entry is accepted (its value

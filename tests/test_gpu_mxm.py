@@ -506,3 +506,47 @@ def test_hyper_switch_conforms_the_result(gba):
     assert product(dBf, B_few, empty.to_hyper(), 0.0625).sparsity == Sparsity.HYPERSPARSE
     for d in (dA, dBf, dBm):
         d.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("by_row", [False, True])
+@pytest.mark.parametrize("accum", [None, "PLUS_FP64"])
+def test_a_hypersparse_inner_dimension_of_2_40(gba, by_row, accum):
+    """C = A*B with an inner dimension of 2^40 that the hypersparse operand lists 300 vectors of: nothing of that
+    size can be built, the reference looks vectors up through the hyper-hash (Source/Shared/GB_hyper_hash_lookup.h:16);
+    here the dimension is renamed to the list.  The other operand has entries at indices the list does not hold (they
+    meet empty vectors).  Expected: the product over the listed indices, formed on the host with scipy."""
+    rng = np.random.default_rng(123)
+    big, m, n, nk = 2**40, 70, 50, 300
+    listed = np.sort(rng.choice(big, nk, replace=False).astype(np.int64))
+    other = np.setdiff1d(rng.choice(big, 200).astype(np.int64), listed)
+    Xs = sp.random(m, nk, density=0.05, random_state=rng, format="csc"); Xs.data = rng.integers(1, 5, len(Xs.data)).astype(np.float64)
+    Xs = Xs[:, np.diff(Xs.indptr) > 0] if False else Xs
+    keep = np.diff(Xs.indptr) > 0                                    # h lists non-empty vectors only
+    Xs, lst = Xs[:, keep].tocsc(), listed[keep]
+    Ys = sp.random(len(lst) + len(other), n, density=0.08, random_state=rng, format="csc")
+    Ys.data = rng.integers(1, 5, len(Ys.data)).astype(np.float64)
+    allk = np.concatenate([lst, other]); order = np.argsort(allk, kind="stable")
+    Ysorted = Ys.tocsr()[order].tocsc(); Ysorted.sort_indices()
+    # the listed operand: vectors over the inner dimension; the other one: indices over it
+    X = Matrix(m, big, Type.FP64, Sparsity.HYPERSPARSE, not by_row, p=Xs.indptr.astype(np.int64), i=Xs.indices.astype(np.int64),
+               x=Xs.data, h=lst)
+    Y = Matrix(big, n, Type.FP64, Sparsity.SPARSE, not by_row, p=Ysorted.indptr.astype(np.int64),
+               i=allk[order][Ysorted.indices].astype(np.int64), x=Ysorted.data)
+    want = (Xs @ Ys.tocsr()[:len(lst)]).toarray()                    # m x n: the listed part of the product
+    C0s = sp.random(m, n, density=0.1, random_state=rng, format="csc"); C0s.data = rng.integers(1, 5, len(C0s.data)).astype(np.float64)
+    if by_row:
+        # the same arrays read by row: X is nk... the product is Y' * X' = (X*Y)', stored by row
+        A, B = Y, X                                                  # A: n x 2^40 by row (long rows), B: 2^40 x m by row, hypersparse
+        C0 = Matrix.from_scipy(C0s.T.tocsr(), type=Type.FP64)        # n x m by row
+        want = want.T
+    else:
+        A, B = X, Y
+        C0 = Matrix.from_scipy(C0s, type=Type.FP64, by_row=False)
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    gba.mxm(dC, None, accum, "PLUS_TIMES_FP64", dA, dB, None)
+    got = dC.to_host().to_scipy().toarray()
+    c0 = C0.to_scipy().toarray()
+    assert np.array_equal(got, c0 + want if accum else want)
+    for d in (dA, dB, dC):
+        d.free()
