@@ -1,0 +1,93 @@
+"""Edge cases of the two places where the front end works on ranks instead of indices: vectors of 2^31 indices or more
+(saxpy3 over the ranks of A's distinct indices) and a hypersparse inner dimension (renamed to the operand's list of
+vectors, Source/Shared/GB_hyper_hash_lookup.h:16 in the reference).  Values are small integers; expected results are
+written out by hand."""
+import numpy as np
+import pytest
+
+from graphblas_amd import Matrix, Type, Sparsity, GrbError, Info
+
+pytestmark = pytest.mark.gpu
+BIG = 2**40
+
+
+def _sparse(vlen, vdim, cols, rows, vals):
+    cols, rows, vals = np.asarray(cols, np.int64), np.asarray(rows, np.int64), np.asarray(vals, np.float64)
+    order = np.lexsort((rows, cols))
+    p = np.zeros(vdim + 1, np.int64)
+    np.add.at(p, cols + 1, 1)
+    return Matrix(vlen, vdim, Type.FP64, Sparsity.SPARSE, True, p=np.cumsum(p), i=rows[order], x=vals[order])
+
+
+def _run(gba, A, B, C0, M=None, accum=None, desc=None, sr="PLUS_TIMES_FP64"):
+    dA, dB, dC = A.to_device(), B.to_device(), C0.to_device()
+    dM = M.to_device() if M is not None else None
+    try:
+        gba.mxm(dC, dM, accum, sr, dA, dB, desc)
+        gba.matrix_wait(dC)
+        return dC.to_host()
+    finally:
+        for d in (dA, dB, dC, dM):
+            if d is not None:
+                d.free()
+
+
+def _entries(out):
+    x = [out.x[0]] * out.nvals if out.iso else np.asarray(out.x).tolist()
+    return sorted(zip(np.repeat(np.arange(out.nvec), np.diff(out.p)).tolist(), out.i.tolist(), x))
+
+
+def _hyper_X():
+    """6 x 2^40 by column, columns 10 and 2^40 - 3 listed."""
+    return Matrix(6, BIG, Type.FP64, Sparsity.HYPERSPARSE, True, p=np.array([0, 2, 3]), i=np.array([1, 4, 2]),
+                  x=np.array([1.0, 2.0, 3.0]), h=np.array([10, BIG - 3]))
+
+
+def test_long_vectors_of_an_operand_without_entries(gba):
+    A = _sparse(BIG, 5, [], [], [])
+    B = _sparse(5, 3, [0, 1], [1, 2], [1, 2])
+    out = _run(gba, A, B, Matrix.sparse_empty(BIG, 3, Type.FP64, by_row=False))
+    assert out.nvals == 0 and out.vlen == BIG
+
+
+@pytest.mark.parametrize("comp", [False, True])
+def test_long_vectors_under_a_mask_without_entries(gba, comp):
+    A = _sparse(BIG, 4, [0, 0, 2], [5, BIG - 1, 7], [1, 2, 3])
+    B = _sparse(4, 2, [0, 1], [0, 2], [2, 5])
+    M0 = Matrix(BIG, 2, Type.BOOL, Sparsity.SPARSE, True, p=np.zeros(3, np.int64), i=np.zeros(0, np.int64), x=np.zeros(0, np.bool_))
+    out = _run(gba, A, B, Matrix.sparse_empty(BIG, 2, Type.FP64, by_row=False), M0, desc="C" if comp else None)
+    assert _entries(out) == ([(0, 5, 2.0), (0, BIG - 1, 4.0), (1, 7, 15.0)] if comp else [])
+
+
+def test_no_index_of_the_other_operand_is_listed(gba):
+    Y = _sparse(BIG, 2, [0, 1], [11, 12], [1, 1])
+    assert _run(gba, _hyper_X(), Y, Matrix.sparse_empty(6, 2, Type.FP64, by_row=False)).nvals == 0
+
+
+def test_an_iso_valued_operand_over_the_renamed_dimension(gba):
+    Y = Matrix(BIG, 2, Type.FP64, Sparsity.SPARSE, True, p=np.array([0, 2, 3]), i=np.array([10, 77, BIG - 3]), x=np.array([5.0]), iso=True)
+    out = _run(gba, _hyper_X(), Y, Matrix.sparse_empty(6, 2, Type.FP64, by_row=False))
+    assert _entries(out) == [(0, 1, 5.0), (0, 4, 10.0), (1, 2, 15.0)]
+
+
+def test_inner_dimensions_that_differ_are_reported_as_such(gba):
+    Y = _sparse(BIG - 1, 2, [0], [10], [1])
+    with pytest.raises(GrbError) as err:
+        _run(gba, _hyper_X(), Y, Matrix.sparse_empty(6, 2, Type.FP64, by_row=False))
+    assert err.value.info == Info.DIMENSION_MISMATCH
+
+
+def test_a_multiplier_that_yields_the_inner_index_sees_the_true_index(gba):
+    """MIN_FIRSTJ: the value is the inner index itself, so that dimension is not renamed."""
+    X = Matrix(6, 1000, Type.FP64, Sparsity.HYPERSPARSE, True, p=np.array([0, 1, 2]), i=np.array([1, 2]), x=np.array([1.0, 1.0]),
+               h=np.array([10, 990]))
+    Y = _sparse(1000, 1, [0, 0], [10, 990], [1, 1])
+    out = _run(gba, X, Y, Matrix.sparse_empty(6, 1, Type.INT64, by_row=False), sr="MIN_FIRSTJ_INT64")
+    assert _entries(out) == [(0, 1, 10), (0, 2, 990)]
+
+
+def test_a_jumbled_operand_with_a_zombie_over_the_renamed_dimension(gba):
+    Y = Matrix(BIG, 1, Type.FP64, Sparsity.SPARSE, True, p=np.array([0, 3]), i=np.array([BIG - 3, -12, 10]), x=np.array([2.0, 9.0, 3.0]),
+               jumbled=True, nzombies=1)
+    out = _run(gba, _hyper_X(), Y, Matrix.sparse_empty(6, 1, Type.FP64, by_row=False))
+    assert _entries(out) == [(0, 1, 3.0), (0, 2, 6.0), (0, 4, 6.0)]
