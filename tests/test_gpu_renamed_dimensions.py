@@ -91,3 +91,21 @@ def test_a_jumbled_operand_with_a_zombie_over_the_renamed_dimension(gba):
                jumbled=True, nzombies=1)
     out = _run(gba, _hyper_X(), Y, Matrix.sparse_empty(6, 1, Type.FP64, by_row=False))
     assert _entries(out) == [(0, 1, 3.0), (0, 2, 6.0), (0, 4, 6.0)]
+
+
+@pytest.mark.parametrize("ckind", ["hypersparse", "iso"])
+def test_an_accumulator_of_another_type_into_a_hypersparse_or_iso_C(gba, ckind):
+    """PLUS_INT32 into an FP64 C (Test/GB_spec_accum.m:45-63): where both have an entry the sum is made in int32 (both
+    truncated); entries of C alone keep their fractions, entries of the product alone are taken as they are."""
+    A = _sparse(4, 3, [0, 0, 2], [0, 3, 1], [1.5, 2.5, 4.5])
+    B = _sparse(3, 5, [1, 1, 4], [0, 2, 2], [2.0, 1.0, 1.0])          # T(:,1) = [3, 4.5, ., 5], T(:,4) = [., 4.5, ., .]
+    if ckind == "hypersparse":
+        C0 = Matrix(4, 5, Type.FP64, Sparsity.HYPERSPARSE, True, p=np.array([0, 2, 3]), i=np.array([0, 2, 1]),
+                    x=np.array([10.75, 20.25, 7.5]), h=np.array([1, 3]))
+        want = [(1, 0, 13.0), (1, 1, 4.5), (1, 2, 20.25), (1, 3, 5.0), (3, 1, 7.5), (4, 1, 4.5)]
+    else:
+        C0 = Matrix(4, 5, Type.FP64, Sparsity.SPARSE, True, p=np.array([0, 0, 2, 2, 3, 3]), i=np.array([0, 2, 1]), x=np.array([10.75]), iso=True)
+        want = [(1, 0, 13.0), (1, 1, 4.5), (1, 2, 10.75), (1, 3, 5.0), (3, 1, 10.75), (4, 1, 4.5)]
+    out = _run(gba, A, B, C0, accum="PLUS_INT32")
+    got = sorted((int(out.h[c]) if out.sparsity == Sparsity.HYPERSPARSE else c, i, x) for c, i, x in _entries(out))
+    assert got == want and out.type == Type.FP64
