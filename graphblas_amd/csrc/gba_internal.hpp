@@ -209,6 +209,8 @@ gba_info to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owne
 constexpr int64_t HYPER_EXPAND_MAX = (int64_t)1 << 31;
 gba_info hyper_to_sparse(const gba_matrix *X, gba_matrix *S, std::vector<void *> &owned);
 gba_info matrix_wait(gba_matrix *C);
+gba_info ranks_in_list(const int64_t *idx, int64_t n, const int64_t *U, int64_t nu, int64_t *out);   // rank in the ascending U, or -1
+gba_info indices_of_ranks(int64_t *idx, int64_t n, const int64_t *U);                              // the way back, in place
 gba_info ranked_copy(const gba_matrix *X, const int64_t *U, int64_t nu, int64_t new_vlen, bool with_values,
                      gba_matrix *out, std::vector<void *> &owned);       // indices -> ranks in U, other entries dropped
 gba_info distinct_sorted(const int64_t *idx, int64_t n, int bits, DevBuf *out, int64_t *count);   // ascending distinct values

@@ -1402,6 +1402,77 @@ static gba_info mxm_real_into_complex(Call k, gba_report *report) {
     return info;
 }
 
+// An outer dimension too large for a pointer per vector (more than 2^31 vectors): C, the operand whose vectors run
+// over the same dimension, and the mask are then all hypersparse, and a vector that none of the three lists stays
+// empty whatever the mask, the accumulator and the descriptor say (no product, no entry of C, no entry of the mask).
+// So the dimension is renamed to the union of the three lists: every list is replaced by its ranks in the union, the
+// call runs on matrices of |union| vectors, and the result's list is turned back into vector numbers.
+struct OuterRename {
+    bool active = false;
+    DevBuf U;
+    int64_t nu = 0, vdim = 0;
+    gba_matrix Xc, Mc;
+    std::vector<void *> owned;
+    ~OuterRename() { for (void *q : owned) gba_free(q); }
+};
+
+static gba_info rename_outer_dimension(Call &k, OuterRename &r) {
+    gba_matrix *C = k.C;
+    if (!C || !is_hyper(C) || C->vdim <= HYPER_EXPAND_MAX || C->mem != GBA_MEM_DEVICE || !k.A_in || !k.B_in) return GBA_SUCCESS;
+    const bool over_n = C->is_csc;                          // C's vectors are its columns
+    const gba_matrix *X = over_n ? k.B_in : k.A_in;
+    const bool x_over = over_n ? (X->is_csc != k.B_transpose) : (X->is_csc == k.A_transpose);
+    auto fits = [&](const gba_matrix *Y) { return is_hyper(Y) && Y->mem == GBA_MEM_DEVICE && Y->vdim == C->vdim && (Y->nvec == 0 || (Y->h && Y->p)); };
+    if (!x_over || !fits(X) || !fits(C)) return GBA_SUCCESS;            // (the call is then declined further down)
+    if (k.M && !(fits(k.M) && k.M->is_csc == C->is_csc)) return GBA_SUCCESS;
+    hipStream_t st = ctx().stream;
+    const int64_t nc = C->nvec, nx = X->nvec, nm = k.M ? k.M->nvec : 0, total = nc + nx + nm;
+    DevBuf cat;
+    GBA_OK(cat.alloc((size_t)(total > 0 ? total : 1) * 8));
+    if (nc) GBA_HIP(hipMemcpyAsync(cat.as<int64_t>(), C->h, (size_t)nc * 8, hipMemcpyDeviceToDevice, st));
+    if (nx) GBA_HIP(hipMemcpyAsync(cat.as<int64_t>() + nc, X->h, (size_t)nx * 8, hipMemcpyDeviceToDevice, st));
+    if (nm) GBA_HIP(hipMemcpyAsync(cat.as<int64_t>() + nc + nx, k.M->h, (size_t)nm * 8, hipMemcpyDeviceToDevice, st));
+    int bits = 1;
+    while (bits < 63 && ((int64_t)1 << bits) < C->vdim) bits++;
+    GBA_OK(distinct_sorted(cat.as<int64_t>(), total, bits, &r.U, &r.nu));
+    const int64_t nv = r.nu > 0 ? r.nu : 1;
+    auto ranked_list = [&](const int64_t *h, int64_t n, int64_t **out) -> gba_info {
+        *out = reinterpret_cast<int64_t *>(gba_malloc((size_t)(n > 0 ? n : 1) * 8));
+        if (!*out) GBA_FAIL(GBA_OUT_OF_MEMORY, "list of %ld vectors", (long)n);
+        return ranks_in_list(h, n, r.U.as<int64_t>(), r.nu, *out);
+    };
+    int64_t *xh = nullptr, *mh = nullptr, *ch = nullptr;
+    GBA_OK(ranked_list(X->h, nx, &xh)); r.owned.push_back(xh);
+    if (k.M) { GBA_OK(ranked_list(k.M->h, nm, &mh)); r.owned.push_back(mh); }
+    GBA_OK(ranked_list(C->h, nc, &ch));
+    GBA_HIP(hipStreamSynchronize(st));
+    r.Xc = *X; r.Xc.h = xh; r.Xc.vdim = nv;
+    if (over_n) k.B_in = &r.Xc; else k.A_in = &r.Xc;
+    if (k.M) { r.Mc = *k.M; r.Mc.h = mh; r.Mc.vdim = nv; k.M = &r.Mc; }
+    r.vdim = C->vdim;
+    gba_free(C->h);                                         // C owns its arrays: its list is replaced, and put back below
+    C->h = ch; C->vdim = nv;
+    r.active = true;
+    return GBA_SUCCESS;
+}
+
+// after the call, successful or not: C is hypersparse again over the true dimension
+static gba_info restore_outer_dimension(gba_matrix *C, OuterRename &r) {
+    if (is_dense_fmt(C)) {                                  // (a product dense enough to have made C bitmap or full)
+        gba_matrix S;
+        std::vector<void *> mine;
+        GBA_OK(to_sparse(C, &S, mine));
+        gba_matrix_free_content(C);
+        *C = S;
+    }
+    if (is_sparse(C)) GBA_OK(sparse_to_hyper(C));
+    if (!is_hyper(C)) GBA_FAIL(GBA_PANIC, "result of sparsity %d over a renamed dimension", C->sparsity);
+    GBA_OK(indices_of_ranks(C->h, C->nvec, r.U.as<int64_t>()));
+    GBA_HIP(hipStreamSynchronize(ctx().stream));
+    C->vdim = r.vdim;
+    return GBA_SUCCESS;
+}
+
 // A C that comes in hypersparse goes back hypersparse: the kernels work on its sparse form (a pointer per vector),
 // and the list of non-empty vectors is rebuilt from the result.
 static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
@@ -1411,6 +1482,18 @@ static gba_info mxm_driver(Call k, gba_report *report, bool select_only) {
     if (is_complex_type(k.semiring.ztype) && !select_only)
         return mxm_complex(k.C, k.M, k.has_accum ? &k.accum : nullptr, &k.semiring, k.A_in, k.A_transpose, k.B_in,
                            k.B_transpose, k.flipxy, k.C_replace, k.Mask_comp, k.Mask_struct, report);
+    OuterRename ren;
+    if (!select_only) GBA_OK(rename_outer_dimension(k, ren));
+    if (ren.active) {
+        const float keep = k.C->hyper_switch;
+        k.C->hyper_switch = 0.0f;                            // the form is not up for choice: only hypersparse holds the true dimension
+        const gba_info info = mxm_driver_sparse_C(k, report, false);
+        const std::string msg = last_error();
+        k.C->hyper_switch = keep;
+        const gba_info back = restore_outer_dimension(k.C, ren);
+        if (info != GBA_SUCCESS) { set_error("%s", msg.c_str()); return info; }
+        return back;
+    }
     const bool C_was_hyper = k.C && is_hyper(k.C);
     const float hs = k.C ? k.C->hyper_switch : 0.0f;         // (a result that replaces C brings its own, zeroed, fields)
     const gba_info info = mxm_driver_sparse_C(k, report, select_only);

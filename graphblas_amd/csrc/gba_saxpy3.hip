@@ -2973,6 +2973,23 @@ ranked_mask_kernel(int64_t nvec, const int64_t *__restrict__ Mp, const int64_t *
     }
 }
 
+// out[e] = the rank of idx[e] in the ascending list U[0..nu), or -1 where the list does not hold it; and the way back
+gba_info ranks_in_list(const int64_t *idx, int64_t n, const int64_t *U, int64_t nu, int64_t *out) {
+    if (n <= 0) return GBA_SUCCESS;
+    int64_t b = ceil_div(n, 256); if (b > 16384) b = 16384;
+    hipLaunchKernelGGL(rank_of_index_kernel, dim3((unsigned)b), dim3(256), 0, ctx().stream, n, idx, U, nu, out);
+    GBA_HIP(hipGetLastError());
+    return GBA_SUCCESS;
+}
+
+gba_info indices_of_ranks(int64_t *idx, int64_t n, const int64_t *U) {
+    if (n <= 0) return GBA_SUCCESS;
+    int64_t b = ceil_div(n, 256); if (b > 16384) b = 16384;
+    hipLaunchKernelGGL(index_of_rank_kernel, dim3((unsigned)b), dim3(256), 0, ctx().stream, n, idx, U);
+    GBA_HIP(hipGetLastError());
+    return GBA_SUCCESS;
+}
+
 // X (sparse or hypersparse) with its indices replaced by their ranks in the ascending list U[0..nu) and the entries
 // at other indices (and zombies) dropped, the rest kept in order: new p and i, a compacted copy of x when the values
 // are wanted and X is not iso-valued (else X's own x), vlen = new_vlen; h, if any, is X's own.  The new arrays are

@@ -255,8 +255,9 @@ void     gba_matrix_free_content(gba_matrix *A);
  * Operands and C of another built-in real type than the semiring's are cast
  * (Source/GB_casting.h rules); hypersparse A, B, M and C are accepted (the
  * inner dimension may have any size: the vectors a hypersparse operand lists
- * are used as they are, Source/Shared/GB_hyper_hash_lookup.h:16; C and M up
- * to 2^31 vectors); a C
+ * are used as they are, Source/Shared/GB_hyper_hash_lookup.h:16; an outer
+ * dimension of more than 2^31 vectors is taken when C, the mask and the
+ * operand that shares it are all hypersparse); a C
  * that is hypersparse on entry is hypersparse on return, any other sparse
  * result stays sparse, unless C->hyper_switch asks for the reference's rule
  * (see gba_matrix).  A C that is iso-valued on entry is accepted (its value

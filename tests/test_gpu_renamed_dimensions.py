@@ -109,3 +109,70 @@ def test_an_accumulator_of_another_type_into_a_hypersparse_or_iso_C(gba, ckind):
     out = _run(gba, A, B, C0, accum="PLUS_INT32")
     got = sorted((int(out.h[c]) if out.sparsity == Sparsity.HYPERSPARSE else c, i, x) for c, i, x in _entries(out))
     assert got == want and out.type == Type.FP64
+
+
+def _hyper_cols(S, cols, vdim, csc, t=Type.FP64):
+    """The CSC matrix S (few columns) as a hypersparse matrix of vdim vectors: column q of S is vector cols[q]."""
+    S = S.tocsc(); S.sort_indices()
+    keep = np.diff(S.indptr) > 0
+    S = S[:, keep].tocsc()
+    return Matrix(S.shape[0], vdim, t, Sparsity.HYPERSPARSE, csc, p=S.indptr.astype(np.int64), i=S.indices.astype(np.int64),
+                  x=S.data.astype(np.float64 if t == Type.FP64 else np.int8), h=np.asarray(cols, np.int64)[keep])
+
+
+@pytest.mark.parametrize("by_row", [False, True])
+@pytest.mark.parametrize("desc,accum,masked", [("", None, False), ("", "PLUS_FP64", False), ("", None, True), ("C", "PLUS_FP64", True),
+                                               ("RS", None, True), ("RC", "MIN_FP64", True)])
+def test_an_outer_dimension_of_2_40_vectors(gba, by_row, desc, accum, masked):
+    """C<M> = accum (C, A*B) where C, the mask and B have 2^40 columns and list a few hundred of them each (or, stored by
+    row, C, the mask and A have 2^40 rows): the dimension is renamed to the union of the three lists.  Expected: the
+    same call on the host over the union (dense arrays, Test/GB_spec_accum_mask.m), the other vectors staying empty."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(321)
+    m, kk, nu = 40, 30, 400
+    union = np.sort(rng.choice(BIG, nu, replace=False).astype(np.int64))
+    def some(density, seed, frac):
+        S = sp.random(m, nu, density=density, random_state=np.random.default_rng(seed), format="csc")
+        S.data = np.random.default_rng(seed + 1).integers(1, 6, len(S.data)).astype(np.float64)
+        drop = np.random.default_rng(seed + 2).random(nu) > frac                       # whole vectors left out of the list
+        S = S.tolil(); S[:, drop] = 0; S = S.tocsc(); S.eliminate_zeros()
+        return S
+    As = sp.random(m, kk, density=0.2, random_state=rng, format="csc"); As.data = rng.integers(1, 4, len(As.data)).astype(np.float64)
+    Bs = sp.random(kk, nu, density=0.1, random_state=rng, format="csc"); Bs.data = rng.integers(1, 4, len(Bs.data)).astype(np.float64)
+    Bl = Bs.tolil(); Bl[:, rng.random(nu) > 0.5] = 0; Bs = Bl.tocsc(); Bs.eliminate_zeros()
+    Cs, Ms = some(0.1, 11, 0.4), some(0.3, 21, 0.6)
+    Ms.data[:] = rng.integers(0, 2, len(Ms.data))                                      # a valued mask with zeros in it
+    # host: dense over the union
+    T = (As @ Bs).toarray(); tin = ((As != 0).astype(int) @ (Bs != 0).astype(int)).toarray() > 0
+    c, cin = Cs.toarray(), (Cs != 0).toarray()
+    if accum == "PLUS_FP64":
+        z, zin = np.where(cin & tin, c + T, np.where(cin, c, T)), cin | tin
+    elif accum == "MIN_FP64":
+        z, zin = np.where(cin & tin, np.minimum(c, T), np.where(cin, c, T)), cin | tin
+    else:
+        z, zin = T, tin
+    if masked:
+        mp = sp.csc_matrix((np.ones(len(Ms.data)), Ms.indices, Ms.indptr), shape=Ms.shape).toarray() > 0
+        mk = mp if "S" in desc else (Ms.toarray() != 0)
+        if "C" in desc:
+            mk = ~mk
+    else:
+        mk = np.ones((m, nu), bool)
+    replace = "R" in desc
+    win = np.where(mk, zin, False if replace else cin)
+    wv = np.where(mk, z, c)
+    # device
+    C0 = _hyper_cols(Cs, union, BIG, True); M = _hyper_cols(Ms, union, BIG, True, Type.INT8) if masked else None
+    B = _hyper_cols(Bs, union, BIG, True); A = Matrix.from_scipy(As, type=Type.FP64, by_row=False)
+    if by_row:
+        # the same arrays read by row are the transposes: C' = B' A', with C', M' and B' of 2^40 rows
+        for X in (C0, M, B, A):
+            if X is not None:
+                X.is_csc = False
+        A, B = B, A
+    out = _run(gba, A, B, C0, M, accum, desc or None)
+    assert out.sparsity == Sparsity.HYPERSPARSE and out.vdim == BIG and out.vlen == m
+    got = sorted((int(out.h[q]), i, x) for q, i, x in _entries(out))
+    r, q = np.nonzero(win)
+    want = sorted((int(union[qq]), int(rr), float(wv[rr, qq])) for rr, qq in zip(r, q))
+    assert got == want
