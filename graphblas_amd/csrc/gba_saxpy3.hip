@@ -210,7 +210,10 @@ static constexpr int NUM_WAVE_SLOTS = 512,   NUM_WAVE_MAX = 256;
 static constexpr int NUM_BLK1_SLOTS = 4096,  NUM_BLK1_MAX = 2048,  NUM_BLK1_THREADS = 256;
 static constexpr int NUM_BLK2_SLOTS = 8192,  NUM_BLK2_MAX = 4096,  NUM_BLK2_THREADS = 512;
 static constexpr int GLOBAL_THREADS = 512;
-static constexpr int SYM_PANEL_MIN = 2048;         // with sorted A the symbolic panel kernel takes every vector of more multiply-adds
+#ifndef GBA_SYM_PANEL_MIN
+#define GBA_SYM_PANEL_MIN 1024
+#endif
+static constexpr int SYM_PANEL_MIN = GBA_SYM_PANEL_MIN;         // with sorted A the symbolic panel kernel takes every vector of more multiply-adds
 // one-pass road for a few light vectors (frontier steps): at most SMALL_NVEC vectors of at most SMALL_ROOM
 // multiply-adds each, accumulated in the second block bin's table (three quarters full at worst)
 static constexpr int SMALL_NVEC = 256, SMALL_ROOM = 6144;
@@ -2751,7 +2754,8 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         P.use_panels = (double)hw[0] >= (double)A->nvals / 8;
     }
     // (measured at RMAT-22: handing the vectors of 2049-4096 multiply-adds to the panel kernel as well saves a quarter of
-    // the first block bin's time, and gives the numeric sweep their boundaries and patterns; at 1024 it costs more)
+    // the first block bin's time, and gives the numeric sweep their boundaries and patterns; since the panel kernel counts
+    // a vector below one stretch in a single hashed walk, 1024 is better still: 358 -> 352 ms of symbolic time; 512: 353)
     const int64_t sym_blk1_max = P.use_panels ? (int64_t)SYM_PANEL_MIN : (int64_t)SYM_BLK1_MAX;
     const int64_t sym_blk2_max = P.use_panels ? (int64_t)SYM_PANEL_MIN : (int64_t)SYM_BLK2_MAX;
     if (!all_team) GBA_OK(build_bins(nvec, symflops, false, BinLimits{SYM_WAVE_MAX, sym_blk1_max, sym_blk2_max}, &P.sym));
