@@ -210,6 +210,9 @@ static constexpr int NUM_WAVE_SLOTS = 512,   NUM_WAVE_MAX = 256;
 static constexpr int NUM_BLK1_SLOTS = 4096,  NUM_BLK1_MAX = 2048,  NUM_BLK1_THREADS = 256;
 static constexpr int NUM_BLK2_SLOTS = 8192,  NUM_BLK2_MAX = 4096,  NUM_BLK2_THREADS = 512;
 static constexpr int GLOBAL_THREADS = 512;
+#ifndef GBA_NUM_PANEL_MIN
+#define GBA_NUM_PANEL_MIN 1024           // with the panel kernels at hand: entries of a vector above which the numeric panel kernel takes it
+#endif
 #ifndef GBA_SYM_PANEL_MIN
 #define GBA_SYM_PANEL_MIN 1024
 #endif
@@ -2838,8 +2841,12 @@ gba_info saxpy3(gba_matrix *C, const gba_matrix *M, bool Mask_comp, bool Mask_st
         }
         // products per thread stay bounded: by flops a vector may need a larger bin than its entry count asks for
         // (with the panel kernel at hand the second block bin stays empty: the panel kernel emits those vectors in a
-        // third of the time)
-        GBA_OK(build_bins(nvec, numwork, false, BinLimits{NUM_WAVE_MAX, NUM_BLK1_MAX, (P.use_panels && P.maxdeg < PANEL_MAX_DEG) ? NUM_BLK1_MAX : NUM_BLK2_MAX}, &P.num,
+        // third of the time; and it takes the vectors of 1025 .. 2048 entries as well -- at RMAT-22 the first block
+        // bin falls from 58 to 9 ms per step for 13 ms more in the panel kernel; from 513 on the panel kernel loses more
+        // than the block bin gains)
+        const bool num_panels = P.use_panels && P.maxdeg < PANEL_MAX_DEG;
+        const int64_t blk1_max = num_panels ? (int64_t)GBA_NUM_PANEL_MIN : (int64_t)NUM_BLK1_MAX;
+        GBA_OK(build_bins(nvec, numwork, false, BinLimits{NUM_WAVE_MAX, blk1_max, num_panels ? blk1_max : (int64_t)NUM_BLK2_MAX}, &P.num,
                           vflops.as<int64_t>(), BinLimits{2048, 16384, 65536}));
     }
     if (P.num.count[BIN_GLOBAL] > 0 && P.maxdeg == 0) GBA_OK(dev_max_diff_i64(B->p, nvec, &P.maxdeg));
